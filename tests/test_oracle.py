@@ -1,0 +1,323 @@
+"""CPU tests that pin the oracle (oracle/) against everything the reference offers for this path:
+the derived geometry of SURVEY.md App. C, the reference's own known-answer test for the window
+query (test/features/feature_tests.cpp:21-50) and the self-consistency checks of SURVEY.md 8(c)."""
+import math
+
+import numpy as np
+import pytest
+
+from orb_slam3_amd import synth
+
+APP_C_640 = [  # (w, h, budget, ncols, nrows, wcell, hcell, nini, kp_size) -- SURVEY.md App. C
+    (640, 480, 217, 20, 14, 31, 32, 1, 31), (533, 400, 181, 16, 12, 32, 31, 1, 37),
+    (444, 333, 151, 13, 10, 32, 31, 1, 44), (370, 278, 126, 11, 8, 31, 31, 1, 53),
+    (309, 231, 105, 9, 6, 31, 34, 1, 64), (257, 193, 87, 7, 5, 33, 33, 1, 77),
+    (214, 161, 73, 6, 4, 31, 33, 1, 92), (179, 134, 60, 4, 3, 37, 34, 1, 111)]
+
+
+def test_geometry_640(oracle):
+    g = oracle.geometry(oracle.params(640, 480), 1000)
+    got = [(g.w[l], g.h[l], g.budget[l], g.ncols[l], g.nrows[l], g.wcell[l], g.hcell[l], g.nini[l], g.kp_size[l])
+           for l in range(8)]
+    assert got == APP_C_640
+    assert sum(g.w[l] * g.h[l] for l in range(8)) == 950532
+
+
+def test_geometry_other_configs(oracle):
+    g = oracle.geometry(oracle.params(512, 512), 1500)
+    assert [g.w[l] for l in range(8)] == [512, 427, 356, 296, 247, 206, 171, 143]
+    assert [g.budget[l] for l in range(8)] == [326, 271, 226, 189, 157, 131, 109, 91]
+    g = oracle.geometry(oracle.params(512, 512), 7500)
+    assert [g.budget[l] for l in range(8)] == [1629, 1357, 1131, 943, 785, 655, 545, 455]
+    g = oracle.geometry(oracle.params(1920, 1080), 5000)
+    assert [g.budget[l] for l in range(8)] == [1086, 905, 754, 628, 524, 436, 364, 303]
+    assert [(g.w[l], g.h[l]) for l in range(8)] == [(1920, 1080), (1600, 900), (1333, 750), (1111, 625), (926, 521),
+                                                    (772, 434), (643, 362), (536, 301)]
+    assert [(g.ncols[l], g.nrows[l], g.wcell[l], g.hcell[l]) for l in (0, 7)] == [(62, 34, 31, 31), (16, 8, 32, 34)]
+    assert g.nini[0] == 2
+    assert sum(g.w[l] * g.h[l] for l in range(8)) == 6419321
+    g = oracle.geometry(oracle.params(3840, 2160), 5000)
+    assert [(g.w[l], g.h[l]) for l in range(8)] == [(3840, 2160), (3200, 1800), (2667, 1500), (2222, 1250),
+                                                    (1852, 1042), (1543, 868), (1286, 723), (1072, 603)]
+    assert (g.ncols[0], g.nrows[0]) == (126, 70)
+    assert sum(g.w[l] * g.h[l] for l in range(8)) == 25677702
+
+
+def test_list_features_in_area_reference_known_answer(oracle):
+    # keypoints and queries of /root/reference/test/features/feature_tests.cpp:21-50
+    pts = [(120, 62, 0), (20, 42, 1), (57, 259, 0), (185, 336, 2), (198, 78, 0), (1, 1, 0), (17, 451, 5),
+           (301, 42, 0), (510, 79, 1), (604, 21, 0), (632, 262, 0)]
+    kps = np.zeros(len(pts), oracle.KP_DTYPE)
+    for i, (x, y, l) in enumerate(pts):
+        kps[i]["x"], kps[i]["y"], kps[i]["level"] = x, y, l
+    assert len(oracle.list_features_in_area(kps, 190, 80, 10, 0, 2)) == 1
+    assert len(oracle.list_features_in_area(kps, 190, 80, 10, 1, 2)) == 0
+    r = oracle.list_features_in_area(kps, 190, 80, 100, 0, 2)
+    assert len(r) == 2 and list(r) == [0, 4]
+    # level rule of features.cpp:94,109-114: (-1,-1) disables the level check, max<0 means open-ended
+    assert len(oracle.list_features_in_area(kps, 0, 0, 10000, -1, -1)) == len(pts)
+    assert list(oracle.list_features_in_area(kps, 0, 0, 10000, 2, -1)) == [3, 6]
+    # strict inequality on the window edge (features.cpp:119)
+    assert len(oracle.list_features_in_area(kps, 188, 78, 10, 0, 0)) == 0
+    assert list(oracle.list_features_in_area(kps, 189, 78, 10, 0, 0)) == [4]
+
+
+@pytest.mark.parametrize("seed,shape", [(1, (40, 52)), (2, (64, 64)), (3, (37, 91))])
+def test_fast_literal_equals_closed_form(oracle, seed, shape):
+    rng = np.random.default_rng(seed)
+    # mix of flat-ish regions and strong edges so both thresholds fire
+    img = (rng.integers(0, 4, shape) * 60 + rng.integers(0, 30, shape)).astype(np.uint8)
+    for thr in (7, 20, 40):
+        x, y, s = oracle.fast_literal(img, thr, True)
+        smap = oracle.fast_score_map(img, thr).astype(np.int32)
+        h, w = shape
+        exp = []
+        for yy in range(3, h - 3):
+            for xx in range(3, w - 3):
+                v = smap[yy, xx]
+                if v < thr:
+                    continue
+                nb = smap[yy - 1:yy + 2, xx - 1:xx + 2].copy()
+                nb[1, 1] = -1
+                if (v > nb).all():
+                    exp.append((xx, yy, v))
+        assert list(zip(x.tolist(), y.tolist(), s.tolist())) == exp
+        assert len(exp) > 0
+        # without NMS every pixel whose closed-form score >= thr is a corner, and only those
+        x2, y2, _ = oracle.fast_literal(img, thr, False)
+        mask = np.zeros(shape, bool)
+        mask[y2, x2] = True
+        assert np.array_equal(mask, smap >= thr)
+
+
+def test_detect_level_literal_equals_scoremap(oracle):
+    img = synth.frame(11, 200, 260)
+    a = oracle.detect_level(img, 20, 7, literal=False)
+    b = oracle.detect_level(img, 20, 7, literal=True)
+    assert len(a) > 50 and np.array_equal(a, b)
+    # low-contrast image: exercises the per-cell fallback to the min threshold
+    low = (img.astype(np.int32) // 6 + 100).astype(np.uint8)
+    a = oracle.detect_level(low, 20, 7, literal=False)
+    b = oracle.detect_level(low, 20, 7, literal=True)
+    assert len(a) > 10 and np.array_equal(a, b)
+    assert a["response"].min() < 20
+
+
+def test_gaussian_blur(oracle):
+    const = np.full((40, 50), 137, np.uint8)
+    assert (oracle.gaussian_blur7(const) == 137).all()
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (48, 70)).astype(np.uint8)
+    out = oracle.gaussian_blur7(img)
+    k = np.array([18, 34, 48, 56, 48, 34, 18], np.float64) / 256
+    assert abs(k.sum() - 1) < 1e-12
+    pad = np.pad(img.astype(np.float64), 3, mode="reflect")  # numpy 'reflect' == BORDER_REFLECT_101
+    hh = sum(k[i] * pad[:, i:i + 70] for i in range(7))
+    vv = sum(k[j] * hh[j:j + 48, :] for j in range(7))
+    assert np.array_equal(out, np.floor(vv + 0.5).astype(np.uint8))
+    # the taps are within rounding of the true sigma=2 Gaussian
+    g = np.exp(-np.arange(-3, 4) ** 2 / 8.0)
+    assert np.abs(k * 256 - g / g.sum() * 256).max() < 1.0
+
+
+def test_resize_close_to_exact_bilinear(oracle):
+    rng = np.random.default_rng(6)
+    src = rng.integers(0, 256, (100, 120)).astype(np.uint8)
+    dw, dh = 100, 83
+    out = oracle.resize_linear(src, dw, dh).astype(np.float64)
+    sx = (np.arange(dw) + 0.5) * (120 / dw) - 0.5
+    sy = (np.arange(dh) + 0.5) * (100 / dh) - 0.5
+    x0 = np.clip(np.floor(sx).astype(int), 0, 118)
+    y0 = np.clip(np.floor(sy).astype(int), 0, 98)
+    fx = np.clip(sx - x0, 0, 1)
+    fy = np.clip(sy - y0, 0, 1)[:, None]
+    s = src.astype(np.float64)
+    ref = (s[y0][:, x0] * (1 - fx) + s[y0][:, x0 + 1] * fx) * (1 - fy) + (s[y0 + 1][:, x0] * (1 - fx) + s[y0 + 1][:, x0 + 1] * fx) * fy
+    assert np.abs(out - ref).max() <= 1.0
+    # identity resize is exact
+    assert np.array_equal(oracle.resize_linear(src, 120, 100), src)
+    # upscale exercises the sx<0 / xmax tail branches; constant image must stay constant
+    c = np.full((20, 30), 77, np.uint8)
+    assert (oracle.resize_linear(c, 47, 33) == 77).all()
+
+
+def test_fast_atan2(oracle):
+    rng = np.random.default_rng(7)
+    for _ in range(2000):
+        y, x = rng.normal(size=2) * 1000
+        ref = math.degrees(math.atan2(y, x)) % 360.0
+        got = oracle.fast_atan2(y, x)
+        d = abs(got - ref)
+        assert min(d, 360 - d) < 0.3
+    assert oracle.fast_atan2(0.0, 0.0) == 0.0
+    assert abs(oracle.fast_atan2(1.0, 0.0) - 90.0) < 1e-3
+
+
+def test_hamming(oracle):
+    rng = np.random.default_rng(8)
+    for _ in range(200):
+        a = rng.integers(0, 256, 32).astype(np.uint8)
+        b = rng.integers(0, 256, 32).astype(np.uint8)
+        assert oracle.hamming256(a, b) == sum(bin(int(v)).count("1") for v in (a ^ b))
+    z = np.zeros(32, np.uint8)
+    assert oracle.hamming256(z, ~z) == 256 and oracle.hamming256(z, z) == 0
+
+
+def _snn_py(to_desc, from_desc, cands, th, ratio):
+    """Literal python transcription of MatchWithIterators' control flow with dicts
+    (second_nearest_neighbor_matcher.hpp:30-80)."""
+    UMAX = 2 ** 32 - 1
+    out, from_to, best_from = {}, {}, {}
+    for i, cj in cands:
+        best = second = UMAX
+        bj = None
+        for j in cj:
+            d = sum(bin(int(v)).count("1") for v in (to_desc[i] ^ from_desc[j]))
+            if d > th:
+                continue
+            if d < best:
+                bj, second, best = j, best, d
+            elif d < second:
+                second = d
+        if best < ratio * second:
+            if bj in best_from:
+                if best_from[bj] > best:
+                    del out[from_to[bj]]
+                else:
+                    continue
+            best_from[bj] = best
+            from_to[bj] = i
+            out[i] = bj
+    return out
+
+
+def test_snn_bruteforce_matches_literal(oracle):
+    rng = np.random.default_rng(9)
+    frm = rng.integers(0, 256, (60, 32)).astype(np.uint8)
+    to = synth.descriptors(10, 80, planted_from=frm, planted_frac=0.7, max_flips=60)
+    to[5] = to[4]  # two 'to' rows claim the same 'from' with equal distance: earliest keeps it
+    frm[11] = frm[10]  # tie between best and second: ratio test must fail
+    for th, ratio in ((50, 0.9), (100, 0.8), (50, 1.0), (100, 0.6), (256, 0.9)):
+        mf, md = oracle.snn_match(to, frm, th, ratio)
+        exp = _snn_py(to, frm, [(i, range(60)) for i in range(80)], th, ratio)
+        got = {i: int(j) for i, j in enumerate(mf) if j >= 0}
+        assert got == exp
+        assert len(set(got.values())) == len(got)
+    assert sum(1 for v in got.values()) > 5
+
+
+def test_snn_window_and_area(oracle):
+    rng = np.random.default_rng(12)
+    n = 70
+    kf = np.zeros(n, oracle.KP_DTYPE)
+    kt = np.zeros(n, oracle.KP_DTYPE)
+    kf["x"] = rng.integers(0, 300, n); kf["y"] = rng.integers(0, 200, n); kf["level"] = rng.integers(0, 3, n)
+    kt["x"] = kf["x"] + rng.integers(-5, 6, n); kt["y"] = kf["y"] + rng.integers(-5, 6, n); kt["level"] = kf["level"]
+    kt["level"][0] = 2
+    df = rng.integers(0, 256, (n, 32)).astype(np.uint8)
+    dt = df.copy()
+    dt[:, 0] ^= rng.integers(0, 256, n).astype(np.uint8)
+    mf, md = oracle.match_area(kt, dt, kf, df, window=30, threshold=50, ratio=0.9)
+    cands = []
+    for i in range(n):
+        if i == 0 or kt["level"][i] == 0:
+            cj = list(oracle.list_features_in_area(kf, kt["x"][i], kt["y"][i], 30, 0, 0))
+            cands.append((i, cj))
+    exp = _snn_py(dt, df, cands, 50, 0.9)
+    assert {i: int(j) for i, j in enumerate(mf) if j >= 0} == exp and len(exp) > 5
+
+
+def _orient_py(ang_to, ang_from, matches):
+    hist = [[] for _ in range(30)]
+    factor = float(np.float32(1.0) / np.float32(30))
+    for i, j in matches.items():
+        rot = np.float32(ang_to[i] - ang_from[j])
+        if rot < 0.0:
+            rot = np.float32(rot + np.float32(360.0))
+        v = float(rot) * factor
+        b = int(math.floor(abs(v) + 0.5) * (1 if v >= 0 else -1))
+        if b == 30:
+            b = 0
+        hist[b].append(i)
+    max1 = max2 = max3 = 0
+    i1 = i2 = i3 = -1
+    for i in range(30):
+        s = len(hist[i])
+        if s > max1:
+            max3, max2, max1, i3, i2, i1 = max2, max1, s, i2, i1, i
+        elif s > max2:
+            max3, max2, i3, i2 = max2, s, i2, i
+        elif s > max3:
+            max3, i3 = s, i
+    if np.float32(max2) < np.float32(0.1) * np.float32(max1):
+        i2 = i3 = -1
+    elif np.float32(max3) < np.float32(0.1) * np.float32(max1):
+        i3 = -1
+    keep = dict(matches)
+    nd = 0
+    for b in range(30):
+        if b in (i1, i2, i3):
+            continue
+        for i in hist[b]:
+            del keep[i]
+            nd += 1
+    return keep, nd
+
+
+def test_orientation_validator(oracle):
+    rng = np.random.default_rng(13)
+    n = 300
+    a_from = np.float32(rng.uniform(0, 360, n)).astype(np.float64)
+    a_to = np.float32((a_from + rng.normal(20, 12, n)) % 360).astype(np.float64)
+    a_to[:40] = np.float32(rng.uniform(0, 360, 40))
+    mf = np.arange(n, dtype=np.int32)
+    mf[rng.random(n) < 0.2] = -1
+    matches = {i: int(j) for i, j in enumerate(mf) if j >= 0}
+    exp, nd = _orient_py(a_to, a_from, matches)
+    got, gnd = oracle.orientation_validate(a_to, a_from, mf)
+    assert gnd == nd and {i: int(j) for i, j in enumerate(got) if j >= 0} == exp
+    assert 0 < nd < len(matches)
+
+
+def test_extract_invariants(oracle):
+    p = oracle.params(320, 240)
+    img = synth.frame(21, 240, 320)
+    kps, desc, ex = oracle.extract(p, img, 500, dump=True)
+    g = ex["geometry"]
+    assert len(kps) == sum(ex["n_kp"]) and len(kps) >= 400
+    # reversed packing (App. B.4): levels descend with index
+    assert (np.diff(kps["level"]) <= 0).all()
+    assert kps["level"][0] == max(l for l in range(8) if ex["n_kp"][l]) and kps["level"][-1] == 0
+    for l in range(8):
+        m = kps["level"] == l
+        assert m.sum() == ex["n_kp"][l] <= g.budget[l] + 3
+        s = float(np.float32(g.scale[l]))
+        lx, ly = kps["x"][m] / (s if l else 1.0), kps["y"][m] / (s if l else 1.0)
+        assert (np.abs(lx - np.round(lx)) < 1e-9).all()
+        assert lx.min() >= 19 - 1e-9 and lx.max() <= g.w[l] - 20 + 1e-9
+        assert ly.min() >= 19 - 1e-9 and ly.max() <= g.h[l] - 20 + 1e-9
+        assert (kps["size"][m] == g.kp_size[l]).all()
+    assert ((kps["angle"] >= 0) & (kps["angle"] < 360)).all()
+    k2, d2 = oracle.extract_literal(p, img, 500)
+    assert np.array_equal(kps, k2) and np.array_equal(desc, d2)
+    # descriptor is recomputable from the dumped blurred level
+    i = len(kps) - 1
+    blur0 = ex["blurred"][:320 * 240].reshape(240, 320)
+    assert np.array_equal(desc[i], oracle.orb_descriptor(blur0, int(kps["x"][i]), int(kps["y"][i]), kps["angle"][i]))
+
+
+def test_extract_edge_cases(oracle):
+    p = oracle.params(160, 120, levels=3)
+    flat = np.full((120, 160), 90, np.uint8)
+    kps, desc = oracle.extract(p, flat, 100)
+    assert len(kps) == 0 and desc.shape == (0, 32)
+    with pytest.raises(ValueError):
+        oracle.geometry(oracle.params(64, 64, levels=8), 100)  # top levels smaller than one 30-px cell
+
+
+def test_predict_scale(oracle):
+    ls = math.log(1.2)
+    for d, m in ((1.0, 1.0), (1.0, 1.3), (2.0, 1.0), (1.0, 100.0), (3.0, 4.0)):
+        e = max(0.0, math.ceil(math.log(m / d) / ls))
+        e = min(int(e), 7)
+        assert oracle.predict_scale(d, m, 1.2, 8) == e
