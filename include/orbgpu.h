@@ -1,0 +1,193 @@
+/*
+ * orbgpu.h -- C ABI of the MI355X-native ORB front-end (liborbgpu.so).
+ *
+ * This is the drop-in boundary for the ORB extraction + descriptor-matching path of
+ * vahagnIV/orb_slam3.  The reference has no FFI layer; its seam is the C++ abstraction
+ * features::IFeatureExtractor (src/features/ifeature_extractor.h:24-60) plus the header-only
+ * matcher features::matching::SNNMatcher<It> (src/features/matching/second_nearest_neighbor_matcher.hpp:19-84)
+ * and features::matching::OrientationValidator (src/features/matching/validators/orientation_validator.h:19-32).
+ * The C++ adapters in orb_slam3_amd/host/ keep those names and signatures and call the entry points
+ * below; INTEGRATION.md shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions: plain pointers and sizes, caller-allocated outputs, int status (0 = ok, < 0 = error,
+ * message via orbgpu_last_error), no exceptions cross the boundary.  Entry points that end in
+ * `_device` take DEVICE pointers (hipMalloc memory on the context's GPU) and run on the context's
+ * stream without synchronising the host unless stated; all others take HOST pointers.
+ * A context serialises its own calls (internal mutex); use one context per calling thread to overlap.
+ * There is no CPU fallback: every entry point fails with ORBGPU_E_HIP when no GPU is usable.
+ */
+#ifndef ORBGPU_H_
+#define ORBGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBGPU_MAX_LEVELS 16
+
+enum {
+  ORBGPU_OK = 0,
+  ORBGPU_E_EMPTY = -1,    /* empty image: the value Extract returns (orb_feature_extractor.cpp:533) */
+  ORBGPU_E_INVALID = -2,  /* bad argument / unsupported geometry */
+  ORBGPU_E_HIP = -3,      /* HIP runtime error or no device */
+  ORBGPU_E_CAPACITY = -4, /* caller buffer or context capacity too small */
+};
+
+typedef struct orbgpu_ctx orbgpu_ctx;
+
+/* Constructor arguments of ORBFeatureExtractor (src/features/orb_feature_extractor.h:24-29) plus
+ * device placement and batch sizing. */
+typedef struct {
+  int32_t width, height;
+  double scale_factor;
+  int32_t levels;
+  int32_t fast_init, fast_min; /* init_threshold_FAST / min_threshold_FAST */
+  int32_t device;              /* HIP device ordinal */
+  int32_t max_batch;           /* frames per orbgpu_extract_batch* call (>= 1) */
+  int32_t max_features;        /* largest feature_count that will be requested per frame */
+} orbgpu_params;
+
+/* features::KeyPoint (src/features/key_point.h:10-23) in wire form.  angle holds the float that
+ * cv::fastAtan2 returned (the reference widens it to double); size = int(31 * scale_factors_[level]). */
+typedef struct {
+  double x, y;
+  float angle;
+  int32_t size;
+  int32_t level;
+  int32_t reserved;
+} orbgpu_keypoint;
+
+/* Derived geometry (orb_feature_extractor.cpp:53-69, 211-242, 506-508); budget is for the
+ * feature_count passed to orbgpu_get_geometry. */
+typedef struct {
+  int32_t levels;
+  int32_t w[ORBGPU_MAX_LEVELS], h[ORBGPU_MAX_LEVELS], budget[ORBGPU_MAX_LEVELS];
+  int32_t ncols[ORBGPU_MAX_LEVELS], nrows[ORBGPU_MAX_LEVELS], wcell[ORBGPU_MAX_LEVELS], hcell[ORBGPU_MAX_LEVELS];
+  int32_t kp_size[ORBGPU_MAX_LEVELS];
+  double scale[ORBGPU_MAX_LEVELS], inv_scale[ORBGPU_MAX_LEVELS], sigma2[ORBGPU_MAX_LEVELS];
+  int64_t pyramid_pixels;     /* P = sum of level pixels */
+  int32_t keypoint_capacity;  /* upper bound of keypoints per frame for this feature_count */
+} orbgpu_geometry;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* replaces: new ORBFeatureExtractor(w, h, scale, levels, initFAST, minFAST)  (main.cpp:451-454,
+ * factories/feature_extractor_factory.cpp:10-17) */
+int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx);
+/* replaces: delete feature_extractor_ (map/atlas.cpp:92-94) */
+void orbgpu_destroy(orbgpu_ctx *ctx);
+/* message of the last failing call on this context (or of a failed orbgpu_create when ctx == NULL) */
+const char *orbgpu_last_error(const orbgpu_ctx *ctx);
+int orbgpu_get_geometry(const orbgpu_ctx *ctx, int32_t feature_count, orbgpu_geometry *out);
+/* the context's HIP stream (hipStream_t) so callers can order their own device work */
+void *orbgpu_stream(orbgpu_ctx *ctx);
+int orbgpu_synchronize(orbgpu_ctx *ctx);
+
+/* ---- extraction ------------------------------------------------------------------------------ */
+/* replaces: IFeatureExtractor::Extract (ifeature_extractor.h:33-35; ORBFeatureExtractor::Extract
+ * orb_feature_extractor.cpp:530-600) for one image.  Keypoints and descriptors come out in the
+ * reference's order (reversed packing, :550,579-587).  *n_out = number of keypoints.
+ * Returns ORBGPU_E_EMPTY for an empty image like the reference's -1. */
+int orbgpu_extract(orbgpu_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride,
+                   int32_t feature_count, orbgpu_keypoint *kp, uint8_t *desc, int32_t capacity, int32_t *n_out);
+/* Same for n_frames images (<= max_batch) in one pass over the GPU; frame f writes kp[f*capacity ...],
+ * desc[f*capacity*32 ...], n_out[f].  The reference calls Extract once per frame
+ * (factories/feature_handler_factory.cpp:50); batching is what the offline workloads use. */
+int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_frames, int32_t stride,
+                         int32_t feature_count, orbgpu_keypoint *kp, uint8_t *desc, int32_t capacity,
+                         int32_t *n_out);
+/* Device-resident form: images, outputs and counts live in HBM.  d_imgs holds n_frames images,
+ * frame f at d_imgs + f*frame_stride, rows `stride` bytes apart.  Synchronises the stream before
+ * returning only while the quadtree stage runs on the host. */
+int orbgpu_extract_batch_device(orbgpu_ctx *ctx, const uint8_t *d_imgs, int64_t frame_stride, int32_t stride,
+                                int32_t n_frames, int32_t feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc,
+                                int32_t capacity, int32_t *d_n_out);
+
+/* Stage dumps of the LAST extract call, for stage-by-stage parity tests (host buffers, packed level
+ * after level with row stride = level width; any pointer may be NULL).  cand_* receive the FAST
+ * candidates of `frame` in reference order (coords relative to the 16-px border). */
+int orbgpu_debug_dump(orbgpu_ctx *ctx, int32_t frame, uint8_t *pyramid, uint8_t *score, uint8_t *blurred,
+                      int32_t *cand_x, int32_t *cand_y, int32_t *cand_score, int32_t cand_capacity,
+                      int32_t *n_cand_per_level);
+
+/* ---- matching -------------------------------------------------------------------------------- */
+/* replaces: IFeatureExtractor::ComputeDistance (ifeature_extractor.h:48, orb_feature_extractor.cpp:83-98)
+ * for host-side callers (map/map_point.cpp:152). */
+static inline uint32_t orbgpu_hamming256(const uint8_t *a, const uint8_t *b) {
+  uint32_t d = 0;
+  for (int i = 0; i < 4; ++i) {
+    uint64_t x, y;
+    __builtin_memcpy(&x, a + 8 * i, 8);
+    __builtin_memcpy(&y, b + 8 * i, 8);
+    d += (uint32_t)__builtin_popcountll(x ^ y);
+  }
+  return d;
+}
+
+/* replaces: SNNMatcher<It>::MatchWithIterators (second_nearest_neighbor_matcher.hpp:30-80) with every
+ * 'from' descriptor as candidate of every 'to' (no candidate restriction).
+ * from_idx_per_to[i] = matched 'from' index or -1; dist[i] = its Hamming distance (undefined when -1). */
+int orbgpu_match_bruteforce(orbgpu_ctx *ctx, const uint8_t *to_desc, int32_t n_to, const uint8_t *from_desc,
+                            int32_t n_from, uint32_t threshold, double ratio, int32_t *from_idx_per_to,
+                            uint32_t *dist);
+int orbgpu_match_bruteforce_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, int32_t n_to,
+                                   const uint8_t *d_from_desc, int32_t n_from, uint32_t threshold, double ratio,
+                                   int32_t *d_from_idx_per_to, uint32_t *d_dist);
+
+/* replaces: the same matcher driven by AreaToIterator (iterators/area_to_iterator.h:16-58) or
+ * ProjectionSearchIterator (iterators/projection_search_iterator.cpp:12-27): candidates of 'to' i are
+ * the 'from' j (ascending j) with level in the range rule of Features::ListFeaturesInArea
+ * (features.cpp:94,109-114) and |x_j - x_i| < window_i, |y_j - y_i| < window_i (strict, double).
+ * to_window is the radius ALREADY truncated to an unsigned integer, as `const size_t&` does at
+ * features.cpp:82.  to_active (optional) = 0 skips a 'to' row (AreaToIterator visits id 0 and every
+ * level-0 id only). */
+typedef struct {
+  const uint8_t *to_desc;      /* n_to x 32 */
+  const double *to_xy;         /* n_to x 2 */
+  const uint64_t *to_window;   /* n_to */
+  const int32_t *to_min_level; /* n_to */
+  const int32_t *to_max_level; /* n_to */
+  const uint8_t *to_active;    /* n_to or NULL */
+  int32_t n_to;
+  const uint8_t *from_desc;    /* n_from x 32 */
+  const double *from_xy;       /* n_from x 2 */
+  const int32_t *from_level;   /* n_from */
+  int32_t n_from;
+  uint32_t threshold;
+  double ratio;
+} orbgpu_window_args;
+int orbgpu_match_window(orbgpu_ctx *ctx, const orbgpu_window_args *args, int32_t *from_idx_per_to, uint32_t *dist);
+int orbgpu_match_window_device(orbgpu_ctx *ctx, const orbgpu_window_args *device_args, int32_t *d_from_idx_per_to,
+                               uint32_t *d_dist);
+
+/* replaces: MonocularFrame::ComputeMatchesForLinking (frame/monocular/monocular_frame.cpp:173-189) for
+ * consecutive frames of a device-resident batch produced by orbgpu_extract_batch_device: for pair p,
+ * 'to' = frame to_frame[p], 'from' = frame from_frame[p]; AreaToIterator window semantics
+ * (level 0 both sides), SNN(ratio, threshold), then, when check_orientation != 0, the
+ * OrientationValidator filter.  d_match is n_pairs x capacity (from index or -1). */
+int orbgpu_match_frames_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp, const uint8_t *d_desc,
+                               const int32_t *d_n, int32_t capacity, const int32_t *d_to_frame,
+                               const int32_t *d_from_frame, int32_t n_pairs, uint64_t window, uint32_t threshold,
+                               double ratio, int32_t check_orientation, int32_t *d_match, uint32_t *d_dist,
+                               int32_t *d_n_matches);
+
+/* replaces: OrientationValidator::Validate (validators/orientation_validator.cpp:16-97).
+ * match[i] >= 0 means 'to' i is matched to 'from' match[i]; discarded matches are set to -1. */
+int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to, const float *angle_from,
+                           int32_t n_from, int32_t *match, int32_t *n_discarded);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* Per-stage GPU time of the last extract call in milliseconds (HIP events on the context's stream):
+ * [0] pyramid [1] fast score [2] cell NMS + compaction [3] quadtree (host wall time or device)
+ * [4] blur [5] orientation + descriptor [6] total.  Used by bench.py for the roofline line. */
+int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms7);
+/* Runs a register-resident XOR + v_bcnt_u32_b32 loop and returns descriptor pairs per second: the
+ * measured popcount ceiling that BASELINE.md asks to report next to the nominal one. */
+int orbgpu_popcount_peak(orbgpu_ctx *ctx, double *pairs_per_second);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBGPU_H_ */

@@ -1,0 +1,99 @@
+"""ctypes loader for liborbgpu.so (the C ABI of include/orbgpu.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is usable this module raises.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "liborbgpu.so"
+
+MAX_LEVELS = 16
+OK, E_EMPTY, E_INVALID, E_HIP, E_CAPACITY = 0, -1, -2, -3, -4
+
+
+class OrbGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"orbgpu error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("scale_factor", C.c_double), ("levels", C.c_int32),
+                ("fast_init", C.c_int32), ("fast_min", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32),
+                ("max_features", C.c_int32)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("levels", C.c_int32)] + \
+               [(n, C.c_int32 * MAX_LEVELS) for n in ("w", "h", "budget", "ncols", "nrows", "wcell", "hcell", "kp_size")] + \
+               [(n, C.c_double * MAX_LEVELS) for n in ("scale", "inv_scale", "sigma2")] + \
+               [("pyramid_pixels", C.c_int64), ("keypoint_capacity", C.c_int32)]
+
+
+class WindowArgs(C.Structure):
+    _fields_ = [("to_desc", C.c_void_p), ("to_xy", C.c_void_p), ("to_window", C.c_void_p), ("to_min_level", C.c_void_p),
+                ("to_max_level", C.c_void_p), ("to_active", C.c_void_p), ("n_to", C.c_int32), ("from_desc", C.c_void_p),
+                ("from_xy", C.c_void_p), ("from_level", C.c_void_p), ("n_from", C.c_int32), ("threshold", C.c_uint32),
+                ("ratio", C.c_double)]
+
+
+KP_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("angle", "<f4"), ("size", "<i4"), ("level", "<i4"), ("reserved", "<i4")])
+assert KP_DTYPE.itemsize == 32
+
+# every symbol include/orbgpu.h declares (the inline orbgpu_hamming256 aside)
+EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_geometry", "orbgpu_stream",
+           "orbgpu_synchronize", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
+           "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_window",
+           "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_rotation_filter", "orbgpu_stage_times",
+           "orbgpu_popcount_peak"]
+
+_lib = None
+
+
+def load():
+    """Load liborbgpu.so; raises if it has not been built (python __graft_entry__.py builds it)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise OrbGpuError(E_HIP, f"{LIB_PATH} is missing: build it with `make -C orb_slam3_amd/csrc` "
+                                 "(there is no CPU fallback)")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i32, u32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_double
+    sig = {
+        "orbgpu_create": (i32, [C.POINTER(Params), C.POINTER(vp)]),
+        "orbgpu_destroy": (None, [vp]),
+        "orbgpu_last_error": (C.c_char_p, [vp]),
+        "orbgpu_get_geometry": (i32, [vp, i32, C.POINTER(Geometry)]),
+        "orbgpu_stream": (vp, [vp]),
+        "orbgpu_synchronize": (i32, [vp]),
+        "orbgpu_extract": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]),
+        "orbgpu_extract_batch": (i32, [vp, C.POINTER(vp), i32, i32, i32, vp, vp, i32, vp]),
+        "orbgpu_extract_batch_device": (i32, [vp, vp, i64, i32, i32, i32, vp, vp, i32, vp]),
+        "orbgpu_debug_dump": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+        "orbgpu_match_bruteforce": (i32, [vp, vp, i32, vp, i32, u32, dbl, vp, vp]),
+        "orbgpu_match_bruteforce_device": (i32, [vp, vp, i32, vp, i32, u32, dbl, vp, vp]),
+        "orbgpu_match_window": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
+        "orbgpu_match_window_device": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
+        "orbgpu_match_frames_device": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, u64, u32, dbl, i32, vp, vp, vp]),
+        "orbgpu_rotation_filter": (i32, [vp, vp, i32, vp, i32, vp, C.POINTER(i32)]),
+        "orbgpu_stage_times": (i32, [vp, vp]),
+        "orbgpu_popcount_peak": (i32, [vp, C.POINTER(dbl)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))

@@ -1,0 +1,710 @@
+// C ABI of liborbgpu.so (include/orbgpu.h): context set-up, derived geometry, resize tables, the
+// extraction pipeline and the host-pointer wrappers of the matching entry points.  gfx950 only.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+#include "orbgpu_internal.h"
+
+static thread_local std::string g_create_error;
+
+int fail(orbgpu_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+int fail_hip(orbgpu_ctx *ctx, hipError_t e, const char *expr, const char *file, int line) {
+  return fail(ctx, ORBGPU_E_HIP,
+              std::string("HIP error '") + hipGetErrorString(e) + "' in " + expr + " at " + file + ":" + std::to_string(line));
+}
+
+namespace {
+
+inline int cv_round_f(float v) { return (int)lrintf(v); }  // cvRound: nearest even
+inline int cv_floor_f(float v) {
+  int i = (int)v;
+  return i - (i > v);
+}
+inline short sat_short(int v) { return (short)std::min(std::max(v, -32768), 32767); }
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// feature budget per level, orb_feature_extractor.cpp:211-224
+void level_budget(double scale_factor, int levels, int n_features, int *budget) {
+  const double factor = 1.0 / scale_factor;
+  double per = (double)(size_t)n_features * (1 - factor) / (1 - std::pow(factor, (double)levels));
+  size_t total = 0;
+  for (int l = 0; l < levels - 1; l++) {
+    budget[l] = (int)std::round(per);
+    total += (size_t)budget[l];
+    per *= factor;
+  }
+  budget[levels - 1] = (int)((size_t)n_features - total);
+}
+
+// Geometry of every level and the device slab layout.  Returns 0 or an error code.
+int build_geometry(orbgpu_ctx *ctx) {
+  const orbgpu_params &p = ctx->params;
+  DeviceGeom &g = ctx->geom;
+  g.levels = p.levels;
+  g.fast_init = p.fast_init;
+  g.fast_min = p.fast_min;
+  // Initialize(), orb_feature_extractor.cpp:53-64
+  ctx->scale[0] = ctx->inv_scale[0] = ctx->sigma2[0] = 1.0;
+  for (int i = 1; i < p.levels; i++) {
+    ctx->scale[i] = ctx->scale[i - 1] * p.scale_factor;
+    ctx->inv_scale[i] = 1.0 / ctx->scale[i];
+    ctx->sigma2[i] = ctx->scale[i] * ctx->scale[i];
+  }
+  int budget[ORBGPU_MAX_LEVELS];
+  level_budget(p.scale_factor, p.levels, p.max_features, budget);
+  unsigned off = 0;
+  int cell_off = 0, cand_off = 0, kp_off = 0, tile_off = 0, xt = 0, yt = 0;
+  for (int l = 0; l < p.levels; l++) {
+    LevelGeom &L = g.lv[l];
+    const float s = (float)ctx->inv_scale[l];  // :506-508
+    L.w = cv_round_f((float)p.width * s);
+    L.h = cv_round_f((float)p.height * s);
+    if (L.w - 2 * ORB_MIN_BORDER < 30 || L.h - 2 * ORB_MIN_BORDER < 30)
+      return fail(ctx, ORBGPU_E_INVALID, "level " + std::to_string(l) + " is smaller than one 30-px FAST cell plus borders");
+    if (L.w - 2 * ORB_MIN_BORDER > 4095 || L.h - 2 * ORB_MIN_BORDER > 4095)
+      return fail(ctx, ORBGPU_E_INVALID, "images wider or taller than 4127 px are not supported (12-bit candidate coordinates)");
+    L.pitch = align_up(L.w, 16);
+    L.off = off;
+    off += (unsigned)align_up(L.pitch * L.h + 64, 256);
+    const float width = (float)(L.w - 2 * ORB_MIN_BORDER), height = (float)(L.h - 2 * ORB_MIN_BORDER);  // :236-242
+    L.ncols = (int)(width / 30.f);
+    L.nrows = (int)(height / 30.f);
+    L.wcell = (int)std::ceil(width / (float)L.ncols);
+    L.hcell = (int)std::ceil(height / (float)L.nrows);
+    if (L.wcell > 64 || L.hcell > 64) return fail(ctx, ORBGPU_E_INVALID, "FAST cell larger than 64 px");
+    L.cell_off = cell_off;
+    cell_off += L.ncols * L.nrows;
+    L.cand_off = cand_off;
+    L.cand_cap = L.ncols * L.nrows * ((L.wcell + 1) / 2) * ((L.hcell + 1) / 2);  // NMS survivors are never adjacent
+    cand_off += align_up(L.cand_cap, 64);
+    ctx->nini[l] = (int)std::round((double)(L.w - 2 * ORB_MIN_BORDER) / (double)(L.h - 2 * ORB_MIN_BORDER));  // :310
+    if (ctx->nini[l] < 1) return fail(ctx, ORBGPU_E_INVALID, "image taller than twice its width: no quadtree root");
+    L.kp_off = kp_off;
+    L.kp_cap = std::max(budget[l], 0) + 4 * ctx->nini[l] + 4;  // the node list overshoots the budget by < 3
+    kp_off += L.kp_cap;
+    L.tile_off = tile_off;
+    tile_off += ((L.w + 127) / 128) * ((L.h + 15) / 16);
+    L.xtab_off = xt;
+    L.ytab_off = yt;
+    xt += L.w;
+    yt += L.h;
+    L.kp_size = (int)(ORB_PATCH * ctx->scale[l]);  // :284
+    L.scale_f = (float)ctx->scale[l];              // :568
+  }
+  g.frame_bytes = off;
+  g.cells_per_frame = cell_off;
+  g.cands_per_frame = cand_off;
+  g.kps_per_frame = kp_off;
+  g.tiles_per_frame = tile_off;
+  return 0;
+}
+
+// cv::resize coefficient tables, one entry per destination column / row of levels >= 1
+int build_resize_tables(orbgpu_ctx *ctx, std::vector<XTab> &xt, std::vector<YTab> &yt) {
+  const DeviceGeom &g = ctx->geom;
+  xt.assign((size_t)g.lv[g.levels - 1].xtab_off + g.lv[g.levels - 1].w, XTab{0, 0, 0, 0});
+  yt.assign((size_t)g.lv[g.levels - 1].ytab_off + g.lv[g.levels - 1].h, YTab{0, 0, 0, 0});
+  for (int l = 1; l < g.levels; l++) {
+    const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = g.lv[l].w, dh = g.lv[l].h;
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1.0 / inv_scale_x, scale_y = 1.0 / inv_scale_y;
+    if (std::fabs(scale_x - 2.0) < 2.3e-16 && std::fabs(scale_y - 2.0) < 2.3e-16)
+      return fail(ctx, ORBGPU_E_INVALID, "exact 2x decimation switches cv::resize to INTER_AREA: unsupported scale_factor");
+    if (scale_x > 2.4 || scale_y > 2.4) return fail(ctx, ORBGPU_E_INVALID, "scale_factor above 2.4 is not supported");
+    for (int dx = 0; dx < dw; dx++) {
+      float fx = (float)((dx + 0.5) * scale_x - 0.5);
+      int sx = cv_floor_f(fx);
+      fx -= sx;
+      if (sx < 0) { fx = 0; sx = 0; }
+      if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+      XTab &X = xt[(size_t)g.lv[l].xtab_off + dx];
+      X.sx0 = sx;
+      X.sx1 = std::min(sx + 1, sw - 1);  // weight is 0 whenever this clamps (the dx >= xmax tail)
+      X.a0 = sat_short(cv_round_f((1.f - fx) * 2048.f));
+      X.a1 = sat_short(cv_round_f(fx * 2048.f));
+    }
+    for (int dy = 0; dy < dh; dy++) {
+      float fy = (float)((dy + 0.5) * scale_y - 0.5);
+      int sy = cv_floor_f(fy);
+      fy -= sy;
+      YTab &Y = yt[(size_t)g.lv[l].ytab_off + dy];
+      Y.sy0 = std::min(std::max(sy, 0), sh - 1);
+      Y.sy1 = std::min(std::max(sy + 1, 0), sh - 1);
+      Y.b0 = sat_short(cv_round_f((1.f - fy) * 2048.f));
+      Y.b1 = sat_short(cv_round_f(fy * 2048.f));
+    }
+  }
+  return 0;
+}
+
+template <class T>
+hipError_t dmalloc(T **p, size_t n) {
+  return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(n, 1) * sizeof(T));
+}
+template <class T>
+hipError_t hmalloc(T **p, size_t n) {
+  return hipHostMalloc(reinterpret_cast<void **>(p), std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault);
+}
+
+int ensure_match_scratch(orbgpu_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->match_scratch_bytes) return 0;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->d_match_scratch) HIP_TRY(hipFree(ctx->d_match_scratch));
+  ctx->d_match_scratch = nullptr;
+  ctx->match_scratch_bytes = 0;
+  bytes = (bytes + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+  HIP_TRY(hipMalloc(&ctx->d_match_scratch, bytes));
+  ctx->match_scratch_bytes = bytes;
+  return 0;
+}
+
+int keypoint_capacity(const orbgpu_ctx *ctx, int feature_count) {
+  int budget[ORBGPU_MAX_LEVELS];
+  level_budget(ctx->params.scale_factor, ctx->params.levels, feature_count, budget);
+  int cap = 0;
+  for (int l = 0; l < ctx->params.levels; l++) cap += std::max(budget[l], 0) + 4 * ctx->nini[l] + 4;
+  return cap;
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b) {
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, a, b);
+  return ms;
+}
+
+// The whole extraction pipeline on device-resident level-0 images already imported into ctx->d_pyr.
+int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
+                 int *d_n_out) {
+  const DeviceGeom &g = ctx->geom;
+  const int L = g.levels;
+  int budget[ORBGPU_MAX_LEVELS];
+  level_budget(ctx->params.scale_factor, L, feature_count, budget);
+
+  HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  for (int l = 1; l < L; l++) launch_pyramid_level(ctx, n_frames, l);
+  HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+  launch_fast_score(ctx, n_frames);
+  HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+  launch_cell_detect(ctx, n_frames);
+  launch_pack_cands(ctx, n_frames);
+  HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+  const int n_fl = n_frames * L;
+  HIP_TRY(hipMemcpyAsync(ctx->h_cand_count, ctx->d_cand_count, sizeof(int) * n_fl, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_cand_prefix, ctx->d_cand_prefix, sizeof(int) * (n_fl + 1), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_cells, ctx->d_cells, sizeof(CellEntry) * (size_t)n_frames * g.cells_per_frame,
+                         hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const size_t total_cands = (size_t)ctx->h_cand_prefix[n_fl];
+  if (total_cands > ctx->h_cands_cap) {
+    if (ctx->h_cands) HIP_TRY(hipHostFree(ctx->h_cands));
+    ctx->h_cands = nullptr;
+    ctx->h_cands_cap = 0;
+    size_t want = total_cands + total_cands / 2 + 4096;
+    HIP_TRY(hmalloc(&ctx->h_cands, want));
+    ctx->h_cands_cap = want;
+  }
+  if (total_cands)
+    HIP_TRY(hipMemcpyAsync(ctx->h_cands, ctx->d_cands_packed, sizeof(unsigned) * total_cands, hipMemcpyDeviceToHost,
+                           ctx->stream));
+  // blur runs on the GPU while the host distributes keypoints
+  HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+  launch_blur(ctx, n_frames);
+  HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
+  // wait for the candidates only (the copy was enqueued before the blur)
+  HIP_TRY(hipEventSynchronize(ctx->ev[4]));
+
+  const auto t0 = std::chrono::steady_clock::now();
+  {
+    // host quadtree, one task per (frame, level), a few worker threads
+    const int n_tasks = n_fl;
+    std::atomic<int> next{0};
+    std::atomic<int> bad{0};
+    auto worker = [&]() {
+      for (;;) {
+        const int t = next.fetch_add(1);
+        if (t >= n_tasks) break;
+        const int f = t / L, l = t % L;
+        const LevelGeom &G = g.lv[l];
+        const int n = quadtree_distribute(ctx->h_cands + ctx->h_cand_prefix[t],
+                                          ctx->h_cells + (size_t)f * g.cells_per_frame + G.cell_off, G.ncols * G.nrows,
+                                          G.w, G.h, budget[l], ctx->h_kp_xy + (size_t)f * g.kps_per_frame + G.kp_off,
+                                          G.kp_cap);
+        if (n < 0 || n > G.kp_cap) {
+          bad.store(1);
+          ctx->h_kp_count[t] = 0;
+        } else {
+          ctx->h_kp_count[t] = n;
+        }
+      }
+    };
+    int n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    n_threads = std::min(n_threads, std::max(1, n_tasks / 4));
+    if (n_threads <= 1) {
+      worker();
+    } else {
+      std::vector<std::thread> pool;
+      for (int i = 0; i < n_threads; i++) pool.emplace_back(worker);
+      for (auto &th : pool) th.join();
+    }
+    if (bad.load()) return fail(ctx, ORBGPU_E_CAPACITY, "quadtree produced more keypoints than the level capacity");
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  HIP_TRY(hipMemcpyAsync(ctx->d_kp_xy, ctx->h_kp_xy, sizeof(short2) * (size_t)n_frames * g.kps_per_frame,
+                         hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->d_kp_count, ctx->h_kp_count, sizeof(int) * n_fl, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
+  launch_orient_describe(ctx, n_frames, d_kp, d_desc, capacity, d_n_out);
+  HIP_TRY(hipEventRecord(ctx->ev[7], ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->stage_ms[0] = elapsed(ctx->ev[0], ctx->ev[1]);
+  ctx->stage_ms[1] = elapsed(ctx->ev[1], ctx->ev[2]);
+  ctx->stage_ms[2] = elapsed(ctx->ev[2], ctx->ev[3]);
+  ctx->stage_ms[3] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  ctx->stage_ms[4] = elapsed(ctx->ev[4], ctx->ev[5]);
+  ctx->stage_ms[5] = elapsed(ctx->ev[6], ctx->ev[7]);
+  ctx->stage_ms[6] = elapsed(ctx->ev[0], ctx->ev[7]);
+  ctx->last_frames = n_frames;
+  ctx->last_feature_count = feature_count;
+  for (int f = 0; f < n_frames; f++) {
+    int tot = 0;
+    for (int l = 0; l < L; l++) tot += ctx->h_kp_count[f * L + l];
+    if (tot > capacity) return fail(ctx, ORBGPU_E_CAPACITY, "keypoint capacity too small: need " + std::to_string(tot));
+  }
+  return 0;
+}
+
+}  // namespace
+
+namespace {
+// host-pointer wrappers stage through one temporary device allocation per call
+struct Staging {
+  orbgpu_ctx *ctx;
+  char *base = nullptr;
+  size_t used = 0, cap = 0;
+  ~Staging() {
+    if (base) (void)hipFree(base);
+  }
+  int reserve(size_t bytes) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), bytes + 4096));
+    cap = bytes + 4096;
+    return 0;
+  }
+  template <class T>
+  T *put(const T *h, size_t n) {
+    used = (used + 255) & ~(size_t)255;
+    T *d = reinterpret_cast<T *>(base + used);
+    used += n * sizeof(T);
+    if (h && n) (void)hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+    return d;
+  }
+};
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+}  // namespace
+
+extern "C" {
+
+int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
+  if (!params || !out_ctx) return fail(nullptr, ORBGPU_E_INVALID, "null argument");
+  *out_ctx = nullptr;
+  if (params->width <= 0 || params->height <= 0) return fail(nullptr, ORBGPU_E_INVALID, "non-positive image size");
+  if (params->levels < 1 || params->levels > ORBGPU_MAX_LEVELS) return fail(nullptr, ORBGPU_E_INVALID, "levels out of range");
+  if (!(params->scale_factor > 1.0)) return fail(nullptr, ORBGPU_E_INVALID, "scale_factor must be > 1");
+  if (params->fast_init < params->fast_min || params->fast_min < 1 || params->fast_init > 255)
+    return fail(nullptr, ORBGPU_E_INVALID, "need 1 <= fast_min <= fast_init <= 255");
+  if (params->max_batch < 1 || params->max_features < 1) return fail(nullptr, ORBGPU_E_INVALID, "max_batch and max_features must be >= 1");
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0 || params->device < 0 || params->device >= n_dev)
+    return fail(nullptr, ORBGPU_E_HIP, "no usable HIP device (this library has no CPU fallback)");
+  orbgpu_ctx *ctx = new orbgpu_ctx();
+  ctx->params = *params;
+  ctx->device = params->device;
+  auto bail = [&](int rc) {
+    g_create_error = ctx->err;
+    orbgpu_destroy(ctx);
+    return rc;
+  };
+  int rc = build_geometry(ctx);
+  if (rc) return bail(rc);
+  std::vector<XTab> xt;
+  std::vector<YTab> yt;
+  rc = build_resize_tables(ctx, xt, yt);
+  if (rc) return bail(rc);
+  const DeviceGeom &g = ctx->geom;
+  const size_t B = (size_t)params->max_batch;
+  auto alloc_all = [&]() -> int {
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (auto &ev : ctx->ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(dmalloc(&ctx->d_pyr, B * g.frame_bytes + 256));
+    HIP_TRY(dmalloc(&ctx->d_score, B * g.frame_bytes + 256));
+    HIP_TRY(dmalloc(&ctx->d_blur, B * g.frame_bytes + 256));
+    HIP_TRY(hipMemsetAsync(ctx->d_pyr, 0, B * g.frame_bytes + 256, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_score, 0, B * g.frame_bytes + 256, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_blur, 0, B * g.frame_bytes + 256, ctx->stream));
+    HIP_TRY(dmalloc(&ctx->d_xtab, xt.size()));
+    HIP_TRY(dmalloc(&ctx->d_ytab, yt.size()));
+    HIP_TRY(hipMemcpyAsync(ctx->d_xtab, xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_ytab, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(dmalloc(&ctx->d_cells, B * g.cells_per_frame));
+    HIP_TRY(dmalloc(&ctx->d_cands, B * g.cands_per_frame));
+    HIP_TRY(dmalloc(&ctx->d_cands_packed, B * g.cands_per_frame));
+    HIP_TRY(dmalloc(&ctx->d_cand_count, B * g.levels));
+    HIP_TRY(dmalloc(&ctx->d_cand_prefix, B * g.levels + 1));
+    HIP_TRY(dmalloc(&ctx->d_kp_xy, B * g.kps_per_frame));
+    HIP_TRY(dmalloc(&ctx->d_kp_count, B * g.levels));
+    ctx->out_capacity = g.kps_per_frame;
+    HIP_TRY(dmalloc(&ctx->d_out_kp, B * ctx->out_capacity));
+    HIP_TRY(dmalloc(&ctx->d_out_desc, B * ctx->out_capacity * 32));
+    HIP_TRY(dmalloc(&ctx->d_out_n, B));
+    HIP_TRY(hmalloc(&ctx->h_cand_count, B * g.levels));
+    HIP_TRY(hmalloc(&ctx->h_cand_prefix, B * g.levels + 1));
+    HIP_TRY(hmalloc(&ctx->h_cells, B * g.cells_per_frame));
+    HIP_TRY(hmalloc(&ctx->h_kp_xy, B * g.kps_per_frame));
+    HIP_TRY(hmalloc(&ctx->h_kp_count, B * g.levels));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // xt/yt are stack-owned
+    return 0;
+  };
+  rc = alloc_all();
+  if (rc) return bail(rc);
+  rc = ensure_match_scratch(ctx, 1u << 20);
+  if (rc) return bail(rc);
+  *out_ctx = ctx;
+  return ORBGPU_OK;
+}
+
+void orbgpu_destroy(orbgpu_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
+                   ctx->d_cands_packed, ctx->d_cand_count, ctx->d_cand_prefix, ctx->d_kp_xy, ctx->d_kp_count,
+                   ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch};
+  for (void *p : dptrs)
+    if (p) (void)hipFree(p);
+  void *hptrs[] = {ctx->h_cand_count, ctx->h_cand_prefix, ctx->h_cells, ctx->h_cands, ctx->h_kp_xy, ctx->h_kp_count, ctx->h_imgs};
+  for (void *p : hptrs)
+    if (p) (void)hipHostFree(p);
+  for (auto &ev : ctx->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *orbgpu_last_error(const orbgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int orbgpu_get_geometry(const orbgpu_ctx *ctx, int32_t feature_count, orbgpu_geometry *out) {
+  if (!ctx || !out || feature_count < 1) return ORBGPU_E_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  const DeviceGeom &g = ctx->geom;
+  out->levels = g.levels;
+  level_budget(ctx->params.scale_factor, g.levels, feature_count, out->budget);
+  for (int l = 0; l < g.levels; l++) {
+    out->w[l] = g.lv[l].w; out->h[l] = g.lv[l].h;
+    out->ncols[l] = g.lv[l].ncols; out->nrows[l] = g.lv[l].nrows;
+    out->wcell[l] = g.lv[l].wcell; out->hcell[l] = g.lv[l].hcell;
+    out->kp_size[l] = g.lv[l].kp_size;
+    out->scale[l] = ctx->scale[l]; out->inv_scale[l] = ctx->inv_scale[l]; out->sigma2[l] = ctx->sigma2[l];
+    out->pyramid_pixels += (int64_t)g.lv[l].w * g.lv[l].h;
+  }
+  out->keypoint_capacity = keypoint_capacity(ctx, feature_count);
+  return ORBGPU_OK;
+}
+
+void *orbgpu_stream(orbgpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int orbgpu_synchronize(orbgpu_ctx *ctx) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ORBGPU_OK;
+}
+
+int orbgpu_extract_batch_device(orbgpu_ctx *ctx, const uint8_t *d_imgs, int64_t frame_stride, int32_t stride,
+                                int32_t n_frames, int32_t feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc,
+                                int32_t capacity, int32_t *d_n_out) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!d_imgs || n_frames <= 0) return fail(ctx, ORBGPU_E_EMPTY, "empty image");
+  if (!d_kp || !d_desc || !d_n_out) return fail(ctx, ORBGPU_E_INVALID, "null output");
+  if (n_frames > ctx->params.max_batch) return fail(ctx, ORBGPU_E_CAPACITY, "n_frames exceeds max_batch");
+  if (feature_count < 1 || feature_count > ctx->params.max_features)
+    return fail(ctx, ORBGPU_E_INVALID, "feature_count outside [1, max_features]");
+  if (stride < ctx->params.width) return fail(ctx, ORBGPU_E_INVALID, "stride smaller than width");
+  if (capacity < 1) return fail(ctx, ORBGPU_E_CAPACITY, "capacity must be >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  launch_import_images(ctx, d_imgs, frame_stride, stride, n_frames);
+  return run_pipeline(ctx, n_frames, feature_count, d_kp, d_desc, capacity, d_n_out);
+}
+
+int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_frames, int32_t stride,
+                         int32_t feature_count, orbgpu_keypoint *kp, uint8_t *desc, int32_t capacity, int32_t *n_out) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!imgs || n_frames <= 0) return fail(ctx, ORBGPU_E_EMPTY, "empty image");
+  for (int f = 0; f < n_frames; f++)
+    if (!imgs[f]) return fail(ctx, ORBGPU_E_EMPTY, "empty image");
+  if (!kp || !desc || !n_out) return fail(ctx, ORBGPU_E_INVALID, "null output");
+  if (n_frames > ctx->params.max_batch) return fail(ctx, ORBGPU_E_CAPACITY, "n_frames exceeds max_batch");
+  if (feature_count < 1 || feature_count > ctx->params.max_features)
+    return fail(ctx, ORBGPU_E_INVALID, "feature_count outside [1, max_features]");
+  const int w = ctx->params.width, h = ctx->params.height;
+  if (stride < w) return fail(ctx, ORBGPU_E_INVALID, "stride smaller than width");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const LevelGeom &L0 = ctx->geom.lv[0];
+  if (!ctx->h_imgs) HIP_TRY(hmalloc(&ctx->h_imgs, (size_t)ctx->params.max_batch * L0.pitch * L0.h));
+  // host -> pinned (pitch layout) -> level 0 of each frame slab
+  for (int f = 0; f < n_frames; f++) {
+    uint8_t *dst = ctx->h_imgs + (size_t)f * L0.pitch * L0.h;
+    for (int y = 0; y < h; y++) {
+      std::memcpy(dst + (size_t)y * L0.pitch, imgs[f] + (size_t)y * stride, (size_t)w);
+      std::memset(dst + (size_t)y * L0.pitch + w, 0, (size_t)(L0.pitch - w));
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->d_pyr + (size_t)f * ctx->geom.frame_bytes + L0.off, dst, (size_t)L0.pitch * L0.h,
+                           hipMemcpyHostToDevice, ctx->stream));
+  }
+  const int cap_dev = ctx->out_capacity;
+  int rc = run_pipeline(ctx, n_frames, feature_count, ctx->d_out_kp, ctx->d_out_desc, cap_dev, ctx->d_out_n);
+  if (rc) return rc;
+  const int L = ctx->geom.levels;
+  for (int f = 0; f < n_frames; f++) {
+    int tot = 0;
+    for (int l = 0; l < L; l++) tot += ctx->h_kp_count[f * L + l];
+    if (tot > capacity) return fail(ctx, ORBGPU_E_CAPACITY, "caller capacity too small: need " + std::to_string(tot));
+    n_out[f] = tot;
+    if (tot) {
+      HIP_TRY(hipMemcpyAsync(kp + (size_t)f * capacity, ctx->d_out_kp + (size_t)f * cap_dev, sizeof(orbgpu_keypoint) * tot,
+                             hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipMemcpyAsync(desc + (size_t)f * capacity * 32, ctx->d_out_desc + (size_t)f * cap_dev * 32, (size_t)tot * 32,
+                             hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ORBGPU_OK;
+}
+
+int orbgpu_extract(orbgpu_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride,
+                   int32_t feature_count, orbgpu_keypoint *kp, uint8_t *desc, int32_t capacity, int32_t *n_out) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  if (!img || width <= 0 || height <= 0) return fail(ctx, ORBGPU_E_EMPTY, "empty image");
+  if (width != ctx->params.width || height != ctx->params.height)
+    return fail(ctx, ORBGPU_E_INVALID, "image size differs from the size the context was created for");
+  const uint8_t *one[1] = {img};
+  return orbgpu_extract_batch(ctx, one, 1, stride, feature_count, kp, desc, capacity, n_out);
+}
+
+int orbgpu_debug_dump(orbgpu_ctx *ctx, int32_t frame, uint8_t *pyramid, uint8_t *score, uint8_t *blurred,
+                      int32_t *cand_x, int32_t *cand_y, int32_t *cand_score, int32_t cand_capacity,
+                      int32_t *n_cand_per_level) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (frame < 0 || frame >= ctx->last_frames) return fail(ctx, ORBGPU_E_INVALID, "frame outside the last batch");
+  const DeviceGeom &g = ctx->geom;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  std::vector<uint8_t> slab(g.frame_bytes);
+  const uint8_t *srcs[3] = {ctx->d_pyr, ctx->d_score, ctx->d_blur};
+  uint8_t *dsts[3] = {pyramid, score, blurred};
+  for (int k = 0; k < 3; k++) {
+    if (!dsts[k]) continue;
+    HIP_TRY(hipMemcpy(slab.data(), srcs[k] + (size_t)frame * g.frame_bytes, g.frame_bytes, hipMemcpyDeviceToHost));
+    size_t o = 0;
+    for (int l = 0; l < g.levels; l++) {
+      const LevelGeom &L = g.lv[l];
+      for (int y = 0; y < L.h; y++) std::memcpy(dsts[k] + o + (size_t)y * L.w, slab.data() + L.off + (size_t)y * L.pitch, (size_t)L.w);
+      o += (size_t)L.w * L.h;
+    }
+  }
+  if (n_cand_per_level || cand_x) {
+    int n = 0;
+    for (int l = 0; l < g.levels; l++) {
+      const int t = frame * g.levels + l;
+      const LevelGeom &L = g.lv[l];
+      const unsigned *c = ctx->h_cands + ctx->h_cand_prefix[t];
+      const CellEntry *cells = ctx->h_cells + (size_t)frame * g.cells_per_frame + L.cell_off;
+      int nl = 0;
+      for (int ci = 0; ci < L.ncols * L.nrows; ci++)
+        for (int k = 0; k < cells[ci].count; k++) {
+          const unsigned v = c[cells[ci].off + k];
+          if (cand_x && n < cand_capacity) {
+            cand_x[n] = (int)(v & 0xfffu);
+            cand_y[n] = (int)((v >> 12) & 0xfffu);
+            cand_score[n] = (int)(v >> 24);
+          }
+          n++;
+          nl++;
+        }
+      if (n_cand_per_level) n_cand_per_level[l] = nl;
+    }
+    if (cand_x && n > cand_capacity) return fail(ctx, ORBGPU_E_CAPACITY, "cand_capacity too small: need " + std::to_string(n));
+  }
+  return ORBGPU_OK;
+}
+
+// ---- matching ----------------------------------------------------------------------------------
+
+static int match_device_locked(orbgpu_ctx *ctx, const orbgpu_window_args &a, int32_t *d_from_idx, uint32_t *d_dist) {
+  if (a.n_to < 0 || a.n_from < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (a.n_from >= (1 << 23)) return fail(ctx, ORBGPU_E_INVALID, "n_from must be below 2^23");
+  if (!(a.ratio >= 0.0)) return fail(ctx, ORBGPU_E_INVALID, "ratio must be >= 0");
+  if (a.n_to == 0) return ORBGPU_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (a.n_from == 0) {
+    HIP_TRY(hipMemsetAsync(d_from_idx, 0xff, sizeof(int32_t) * (size_t)a.n_to, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_dist, 0, sizeof(uint32_t) * (size_t)a.n_to, ctx->stream));
+    return ORBGPU_OK;
+  }
+  int rc = ensure_match_scratch(ctx, match_scratch_size(a.n_to, a.n_from));
+  if (rc) return rc;
+  launch_match(ctx, a, d_from_idx, d_dist, ctx->d_match_scratch);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
+int orbgpu_match_bruteforce_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, int32_t n_to, const uint8_t *d_from_desc,
+                                   int32_t n_from, uint32_t threshold, double ratio, int32_t *d_from_idx_per_to,
+                                   uint32_t *d_dist) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if ((n_to > 0 && (!d_to_desc || !d_from_idx_per_to || !d_dist)) || (n_from > 0 && !d_from_desc))
+    return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  orbgpu_window_args a{};
+  a.to_desc = d_to_desc; a.n_to = n_to; a.from_desc = d_from_desc; a.n_from = n_from;
+  a.threshold = threshold; a.ratio = ratio;
+  return match_device_locked(ctx, a, d_from_idx_per_to, d_dist);
+}
+
+int orbgpu_match_window_device(orbgpu_ctx *ctx, const orbgpu_window_args *a, int32_t *d_from_idx_per_to, uint32_t *d_dist) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_to > 0 && (!a->to_desc || !a->to_xy || !a->to_window || !a->to_min_level || !a->to_max_level ||
+                      !d_from_idx_per_to || !d_dist))
+    return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_from > 0 && (!a->from_desc || !a->from_xy || !a->from_level)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  return match_device_locked(ctx, *a, d_from_idx_per_to, d_dist);
+}
+
+
+int orbgpu_match_window(orbgpu_ctx *ctx, const orbgpu_window_args *a, int32_t *from_idx_per_to, uint32_t *dist) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  const bool window = a->to_xy != nullptr;
+  if (a->n_to < 0 || a->n_from < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (a->n_to > 0 && (!a->to_desc || !from_idx_per_to || !dist)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_from > 0 && !a->from_desc) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (window && a->n_to > 0 && (!a->to_window || !a->to_min_level || !a->to_max_level)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (window && a->n_from > 0 && (!a->from_xy || !a->from_level)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_to == 0) return ORBGPU_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t nt = (size_t)a->n_to, nf = (size_t)a->n_from;
+  Staging st{ctx};
+  int rc = st.reserve(pad256(nt * 32) + pad256(nf * 32) + pad256(nt * 16) + pad256(nt * 8) + 2 * pad256(nt * 4) + pad256(nt) +
+                      pad256(nf * 16) + pad256(nf * 4) + 2 * pad256(nt * 4) + 4096);
+  if (rc) return rc;
+  orbgpu_window_args d = *a;
+  d.to_desc = st.put(a->to_desc, nt * 32);
+  d.from_desc = st.put(a->from_desc, nf * 32);
+  if (window) {
+    d.to_xy = st.put(a->to_xy, nt * 2);
+    d.to_window = st.put(a->to_window, nt);
+    d.to_min_level = st.put(a->to_min_level, nt);
+    d.to_max_level = st.put(a->to_max_level, nt);
+    d.from_xy = st.put(a->from_xy, nf * 2);
+    d.from_level = st.put(a->from_level, nf);
+  }
+  d.to_active = a->to_active ? st.put(a->to_active, nt) : nullptr;
+  int32_t *d_idx = st.put<int32_t>(nullptr, nt);
+  uint32_t *d_dist = st.put<uint32_t>(nullptr, nt);
+  rc = match_device_locked(ctx, d, d_idx, d_dist);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(from_idx_per_to, d_idx, nt * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dist, d_dist, nt * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ORBGPU_OK;
+}
+
+int orbgpu_match_bruteforce(orbgpu_ctx *ctx, const uint8_t *to_desc, int32_t n_to, const uint8_t *from_desc, int32_t n_from,
+                            uint32_t threshold, double ratio, int32_t *from_idx_per_to, uint32_t *dist) {
+  orbgpu_window_args a{};
+  a.to_desc = to_desc; a.n_to = n_to; a.from_desc = from_desc; a.n_from = n_from;
+  a.threshold = threshold; a.ratio = ratio;
+  return orbgpu_match_window(ctx, &a, from_idx_per_to, dist);
+}
+
+int orbgpu_match_frames_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp, const uint8_t *d_desc, const int32_t *d_n,
+                               int32_t capacity, const int32_t *d_to_frame, const int32_t *d_from_frame, int32_t n_pairs,
+                               uint64_t window, uint32_t threshold, double ratio, int32_t check_orientation,
+                               int32_t *d_match, uint32_t *d_dist, int32_t *d_n_matches) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (n_pairs < 0 || capacity < 1) return fail(ctx, ORBGPU_E_INVALID, "bad size");
+  if (n_pairs == 0) return ORBGPU_OK;
+  if (!d_kp || !d_desc || !d_n || !d_to_frame || !d_from_frame || !d_match || !d_dist || !d_n_matches)
+    return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (capacity >= (1 << 23)) return fail(ctx, ORBGPU_E_INVALID, "capacity must be below 2^23");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int n_chunks = (capacity + 255) / 256;
+  const size_t bytes = (size_t)n_pairs * capacity * 8 + (size_t)n_pairs * n_chunks * capacity * 8 + 256;
+  int rc = ensure_match_scratch(ctx, bytes);
+  if (rc) return rc;
+  launch_match_frames(ctx, d_kp, d_desc, d_n, capacity, d_to_frame, d_from_frame, n_pairs, window, threshold, ratio,
+                      check_orientation, d_match, d_dist, d_n_matches);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
+int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to, const float *angle_from, int32_t n_from,
+                           int32_t *match, int32_t *n_discarded) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (n_to < 0 || n_from < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (n_discarded) *n_discarded = 0;
+  if (n_to == 0) return ORBGPU_OK;
+  if (!angle_to || !match || (n_from > 0 && !angle_from)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  for (int i = 0; i < n_to; i++)
+    if (match[i] >= n_from) return fail(ctx, ORBGPU_E_INVALID, "match index outside [0, n_from)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  Staging st{ctx};
+  int rc = st.reserve(pad256((size_t)n_to * 4) * 2 + pad256((size_t)n_from * 4) + 1024);
+  if (rc) return rc;
+  float *d_to = st.put(angle_to, (size_t)n_to);
+  float *d_from = st.put(angle_from, (size_t)n_from);
+  int32_t *d_m = st.put(match, (size_t)n_to);
+  int32_t *d_nd = st.put<int32_t>(nullptr, 1);
+  launch_rotation_filter(ctx, d_to, n_to, d_from, d_m, d_nd);
+  HIP_TRY(hipGetLastError());
+  int32_t nd = 0;
+  HIP_TRY(hipMemcpyAsync(match, d_m, (size_t)n_to * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&nd, d_nd, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (n_discarded) *n_discarded = nd;
+  return ORBGPU_OK;
+}
+
+int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms7) {
+  if (!ctx || !ms7) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  for (int i = 0; i < 7; i++) ms7[i] = ctx->stage_ms[i];
+  return ORBGPU_OK;
+}
+
+int orbgpu_popcount_peak(orbgpu_ctx *ctx, double *pairs_per_second) {
+  if (!ctx || !pairs_per_second) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  *pairs_per_second = run_popcount_peak(ctx);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
+}  // extern "C"

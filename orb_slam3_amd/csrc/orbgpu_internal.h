@@ -1,0 +1,132 @@
+// Internal declarations shared by the HIP translation units of liborbgpu.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/orbgpu.h"
+
+#define ORB_EDGE 19        // EDGE_THRESHOLD, src/features/orb_feature_extractor.h:20
+#define ORB_HALF_PATCH 15  // :18
+#define ORB_PATCH 31       // :19
+#define ORB_MIN_BORDER 16  // EDGE_THRESHOLD - 3, orb_feature_extractor.cpp:228
+
+// One pyramid level as the kernels see it.  All images of a frame (pyramid, score, blurred) share
+// this layout: level l starts `off` bytes into the frame slab, rows are `pitch` bytes apart.
+struct LevelGeom {
+  int w, h, pitch;
+  unsigned off;
+  int ncols, nrows, wcell, hcell;  // FAST cell grid, orb_feature_extractor.cpp:236-242
+  int cell_off;                    // first cell of this level in a frame's cell table
+  int cand_off, cand_cap;          // candidate sub-pool (u32 entries) inside a frame's candidate slab
+  int kp_off, kp_cap;              // keypoint slots of this level inside a frame's keypoint slab
+  int tile_off;                    // first 128x16 tile of this level in the all-level tile index
+  int xtab_off, ytab_off;          // resize coefficient tables (entries)
+  int kp_size;                     // int(31 * scale_factors_[l])
+  float scale_f;                   // (float)scale_factors_[l]
+};
+
+struct DeviceGeom {
+  int levels;
+  int fast_init, fast_min;
+  unsigned frame_bytes;   // bytes of one frame slab
+  int cells_per_frame;
+  int cands_per_frame;
+  int kps_per_frame;      // sum of kp_cap
+  int tiles_per_frame;
+  LevelGeom lv[ORBGPU_MAX_LEVELS];
+};
+
+// resize tables: built on the host in the exact float/double sequence
+struct XTab { int sx0, sx1; short a0, a1; };
+struct YTab { int sy0, sy1; short b0, b1; };
+
+// packed FAST candidate: x_rel | y_rel << 12 | score << 24, coordinates relative to ORB_MIN_BORDER
+__host__ __device__ inline unsigned pack_cand(int x, int y, int s) { return (unsigned)x | ((unsigned)y << 12) | ((unsigned)s << 24); }
+
+struct CellEntry { int off, count; };  // segment of a (frame, level) candidate sub-pool
+
+#define HIP_TRY(expr)                                                             \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr, __FILE__, __LINE__);    \
+  } while (0)
+
+struct orbgpu_ctx {
+  orbgpu_params params{};
+  DeviceGeom geom{};
+  double scale[ORBGPU_MAX_LEVELS]{}, inv_scale[ORBGPU_MAX_LEVELS]{}, sigma2[ORBGPU_MAX_LEVELS]{};
+  int nini[ORBGPU_MAX_LEVELS]{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::string err;
+
+  // device slabs, sized for max_batch frames
+  uint8_t *d_pyr = nullptr, *d_score = nullptr, *d_blur = nullptr;
+  XTab *d_xtab = nullptr;
+  YTab *d_ytab = nullptr;
+  CellEntry *d_cells = nullptr;   // [frame][cells_per_frame]
+  unsigned *d_cands = nullptr;    // [frame][cands_per_frame]
+  int *d_cand_count = nullptr;    // [frame][levels]
+  int *d_cand_prefix = nullptr;   // [frame*levels + 1] exclusive scan of d_cand_count
+  unsigned *d_cands_packed = nullptr;  // dense copy for the host quadtree
+  short2 *d_kp_xy = nullptr;      // [frame][kps_per_frame] level coordinates after the quadtree
+  int *d_kp_count = nullptr;      // [frame][levels]
+  // internal outputs used by the host-pointer entry points
+  orbgpu_keypoint *d_out_kp = nullptr;
+  uint8_t *d_out_desc = nullptr;
+  int *d_out_n = nullptr;
+  int out_capacity = 0;
+
+  // pinned host staging
+  int *h_cand_count = nullptr, *h_cand_prefix = nullptr;
+  CellEntry *h_cells = nullptr;
+  unsigned *h_cands = nullptr;
+  size_t h_cands_cap = 0;
+  short2 *h_kp_xy = nullptr;
+  int *h_kp_count = nullptr;
+  uint8_t *h_imgs = nullptr;  // pinned upload buffer for host-pointer extraction
+
+  // matching scratch (grown on demand)
+  void *d_match_scratch = nullptr;
+  size_t match_scratch_bytes = 0;
+
+  hipEvent_t ev[8]{};
+  float stage_ms[7]{};
+  int last_frames = 0;
+  int last_feature_count = 0;
+};
+
+int fail(orbgpu_ctx *ctx, int code, const std::string &msg);
+int fail_hip(orbgpu_ctx *ctx, hipError_t e, const char *expr, const char *file, int line);
+
+// ---- kernel launchers (each defined next to its kernels) ----
+void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level);
+void launch_fast_score(const orbgpu_ctx *c, int n_frames);
+void launch_cell_detect(const orbgpu_ctx *c, int n_frames);
+void launch_pack_cands(const orbgpu_ctx *c, int n_frames);
+void launch_blur(const orbgpu_ctx *c, int n_frames);
+void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
+                            int *d_n_out);
+void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t frame_stride, int stride, int n_frames);
+
+// host quadtree (DistributeOctTree), flat-array formulation; returns number of keypoints written
+int quadtree_distribute(const unsigned *cands, const CellEntry *cells, int n_cells, int w, int h, int n_features,
+                        short2 *out_xy, int out_cap);
+
+// matching
+size_t match_scratch_size(int n_to, int n_from);
+void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a /* device pointers; to_xy==NULL => brute force */,
+                  int *d_from_idx, unsigned *d_dist, void *scratch);
+void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const uint8_t *d_desc, const int *d_n,
+                         int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
+                         unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,
+                         int *d_n_matches);
+void launch_rotation_filter(const orbgpu_ctx *c, const float *d_ang_to, int n_to, const float *d_ang_from, int *d_match,
+                            int *d_n_discarded);
+double run_popcount_peak(const orbgpu_ctx *c);
