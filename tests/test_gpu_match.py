@@ -1,0 +1,164 @@
+"""GPU parity of the matching path (through the C ABI) against the CPU oracle: brute-force SNN, windowed
+(AreaTo / ProjectionSearch) SNN, uniqueness, rotation histogram.  Match sets must be identical."""
+import numpy as np
+import pytest
+
+from orb_slam3_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe():
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    e = ORBFeatureExtractor(640, 480, 1.2, 8, 20, 7, max_features=1000)
+    yield e
+    e.close()
+
+
+def _as_dict(idx):
+    return {i: int(j) for i, j in enumerate(idx) if j >= 0}
+
+
+@pytest.mark.parametrize("n_to,n_from", [(1, 1), (80, 60), (1000, 1000), (3000, 257), (65, 5000)])
+@pytest.mark.parametrize("th,ratio", [(50, 0.9), (100, 0.8), (50, 1.0), (100, 0.6)])
+def test_bruteforce_parity(oracle, fe, n_to, n_from, th, ratio):
+    from orb_slam3_amd.features import SNNMatcher
+    frm = synth.descriptors(100 + n_from, n_from)
+    to = synth.descriptors(200 + n_to, n_to, planted_from=frm, planted_frac=0.6, max_flips=70)
+    if n_to > 10 and n_from > 12:
+        to[5] = to[4]        # equal claims on one 'from': earliest 'to' keeps it
+        frm[11] = frm[10]    # best == second: ratio test fails
+    omf, omd = oracle.snn_match(to, frm, th, ratio)
+    m = SNNMatcher(ratio, th, fe)
+    gidx, gdist = m.MatchRaw(to, frm)
+    assert np.array_equal(gidx, omf)
+    sel = omf >= 0
+    assert np.array_equal(gdist[sel], omd[sel])
+    assert m.MatchBruteForce(to, frm) == _as_dict(omf)
+
+
+def test_bruteforce_edge_cases(oracle, fe):
+    from orb_slam3_amd.features import SNNMatcher
+    m = SNNMatcher(0.9, 50, fe)
+    frm = synth.descriptors(1, 10)
+    assert m.MatchBruteForce(np.zeros((0, 32), np.uint8), frm) == {}
+    assert m.MatchBruteForce(frm, np.zeros((0, 32), np.uint8)) == {}
+    # identical sets: everything matches itself at distance 0 (0 < 0.9 * second unless second == 0)
+    got = m.MatchBruteForce(frm, frm)
+    assert got == {i: i for i in range(10)}
+    # all-equal descriptors: best == second == 0 -> nothing passes
+    same = np.repeat(frm[:1], 7, 0)
+    assert m.MatchBruteForce(same, same) == {}
+    # a single candidate passes the ratio test against UINT_MAX
+    assert m.MatchBruteForce(frm[:3], frm[:1]) == {0: 0}
+
+
+def _random_features(rng, n, w=640, h=480):
+    from orb_slam3_amd.features import Features
+    from orb_slam3_amd._lib import KP_DTYPE
+    f = Features(w, h)
+    k = np.zeros(n, KP_DTYPE)
+    lv = rng.integers(0, 4, n)
+    sc = np.float32(1.2) ** lv
+    k["x"] = rng.integers(19, w - 19, n) * sc.astype(np.float64)
+    k["y"] = rng.integers(19, h - 19, n) * sc.astype(np.float64)
+    k["level"] = lv
+    k["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    f.keypoints = k
+    f.descriptors = rng.integers(0, 256, (n, 32)).astype(np.uint8)
+    return f
+
+
+def _to_oracle_kp(oracle, k):
+    o = np.zeros(len(k), oracle.KP_DTYPE)
+    for n in ("x", "y", "level"):
+        o[n] = k[n]
+    o["angle"] = k["angle"].astype(np.float64)
+    o["size"] = k["size"]
+    return o
+
+
+@pytest.mark.parametrize("n,window,seed", [(300, 30, 1), (1000, 100, 2), (1000, 15, 3)])
+def test_area_parity(oracle, fe, n, window, seed):
+    from orb_slam3_amd.features import SNNMatcher
+    rng = np.random.default_rng(seed)
+    ff = _random_features(rng, n)
+    ft = _random_features(rng, n)
+    # make 'to' a jittered copy of 'from' so matches exist
+    ft.keypoints["x"] = ff.keypoints["x"] + rng.integers(-6, 7, n)
+    ft.keypoints["y"] = ff.keypoints["y"] + rng.integers(-6, 7, n)
+    ft.keypoints["level"] = ff.keypoints["level"]
+    ft.descriptors = ff.descriptors.copy()
+    flips = rng.integers(0, 256, (n, 3)).astype(np.uint8)
+    ft.descriptors[:, :3] ^= flips
+    ft.keypoints["level"][0] = 2  # id 0 is visited whatever its level
+    omf, omd = oracle.match_area(_to_oracle_kp(oracle, ft.keypoints), ft.descriptors,
+                                 _to_oracle_kp(oracle, ff.keypoints), ff.descriptors, window, 50, 0.9)
+    got = SNNMatcher(0.9, 50, fe).MatchArea(ft, ff, window)
+    assert got == _as_dict(omf) and len(got) > 10
+
+
+@pytest.mark.parametrize("radius", [15.0, 30.0, 7.9])
+def test_projection_parity(oracle, fe, radius):
+    from orb_slam3_amd.features import SNNMatcher
+    rng = np.random.default_rng(11)
+    n = 800
+    ff = _random_features(rng, n)
+    vis = []
+    sel = rng.choice(n, 400, replace=False)
+    for j in sel:
+        d = ff.descriptors[j].copy()
+        d[:2] ^= rng.integers(0, 256, 2).astype(np.uint8)
+        lvl = int(ff.keypoints["level"][j]) + int(rng.integers(-1, 2))
+        vis.append({"descriptor": d, "position": (ff.keypoints["x"][j] + rng.uniform(-4, 4), ff.keypoints["y"][j] + rng.uniform(-4, 4)),
+                    "window_size": radius * float(np.float32(1.2) ** max(lvl, 0)), "level": max(lvl, 0)})
+    got = SNNMatcher(0.9, 100, fe).MatchProjection(vis, ff)
+    desc = np.stack([v["descriptor"] for v in vis])
+    xy = np.array([v["position"] for v in vis])
+    win = np.array([int(v["window_size"]) for v in vis], np.uint64)
+    lv = np.array([v["level"] for v in vis], np.int32)
+    kf = ff.keypoints
+    omf, _ = oracle.snn_match(desc, ff.descriptors, 100, 0.9, to_xy=xy, to_window=win, to_min_level=np.maximum(lv - 1, 0),
+                              to_max_level=lv + 1, from_xy=np.stack([kf["x"], kf["y"]], 1), from_level=kf["level"])
+    assert got == _as_dict(omf) and len(got) > 50
+
+
+def test_rotation_filter_parity(oracle, fe):
+    from orb_slam3_amd.features import OrientationValidator
+    rng = np.random.default_rng(13)
+    for n, noise in ((300, 12.0), (50, 40.0), (1000, 3.0)):
+        ff = _random_features(rng, n)
+        ft = _random_features(rng, n)
+        ft.keypoints["angle"] = ((ff.keypoints["angle"] + rng.normal(20, noise, n)) % 360).astype(np.float32)
+        ft.keypoints["angle"][: n // 8] = rng.uniform(0, 360, n // 8).astype(np.float32)
+        matches = {int(i): int(i) for i in np.nonzero(rng.random(n) < 0.8)[0]}
+        mf = np.full(n, -1, np.int32)
+        for i, j in matches.items():
+            mf[i] = j
+        exp, end = oracle.orientation_validate(ft.keypoints["angle"].astype(np.float64),
+                                               ff.keypoints["angle"].astype(np.float64), mf)
+        got = dict(matches)
+        nd = OrientationValidator(ft.keypoints, ff.keypoints, fe).Validate(got)
+        assert nd == end and got == _as_dict(exp)
+    assert OrientationValidator(ft.keypoints[:0], ff.keypoints[:0], fe).Validate({}) == 0
+
+
+def test_extract_then_link_end_to_end(oracle):
+    """extract two consecutive synthetic frames on the GPU, link them (window 100, 0.9 / 50 + rotation filter) and
+    compare with the oracle run on the oracle's own extraction: MonocularFrame::ComputeMatchesForLinking."""
+    from orb_slam3_amd.features import ORBFeatureExtractor, SNNMatcher, OrientationValidator
+    frames = synth.sequence(1234, 2)
+    fe = ORBFeatureExtractor(640, 480, 1.2, 8, 20, 7, max_batch=2, max_features=1000)
+    f_from, f_to = fe.ExtractBatch([frames[0], frames[1]], 1000)
+    p = oracle.params(640, 480)
+    ok_from, od_from = oracle.extract(p, frames[0], 1000)
+    ok_to, od_to = oracle.extract(p, frames[1], 1000)
+    assert np.array_equal(f_to.descriptors, od_to) and np.array_equal(f_from.descriptors, od_from)
+    got = SNNMatcher(0.9, 50, fe).MatchArea(f_to, f_from, 100)
+    nd = OrientationValidator(f_to.keypoints, f_from.keypoints, fe).Validate(got)
+    omf, _ = oracle.match_area(ok_to, od_to, ok_from, od_from, 100, 50, 0.9)
+    omf, ond = oracle.orientation_validate(ok_to["angle"], ok_from["angle"], omf)
+    assert got == _as_dict(omf) and nd == ond
+    assert len(got) >= 100  # the reference needs >= 100 matches to link (monocular_frame.cpp:195)
+    fe.close()
