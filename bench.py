@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- ORB extract + guided match throughput on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
+  orbgpu_extract_batch_device (pyramid, FAST, cells, quadtree, blur, orientation, rBRIEF) for every frame of the
+  batch, then orbgpu_match_frames_device linking frame t to frame t-1 (window 100, ratio 0.9, TH 50, rotation
+  histogram) -- the reference's per-frame Extract + ComputeMatchesForLinking.
+Workload at N=1: BASELINE.json configs[1], 256 synthetic 640x480 frames, 8 levels, 1000 keypoints.
+N>1: frames shard by rank (contiguous blocks, no data-path collective), weak scaling.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--features", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bruteforce", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from orb_slam3_amd import _lib, synth
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    W, H, NF, B = args.width, args.height, args.features, args.frames
+    fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, device=local_rank, max_batch=B, max_features=NF)
+    g = fe.geometry(NF)
+    cap = g.keypoint_capacity
+    P = int(g.pyramid_pixels)
+
+    # synthetic TUM-shaped sequence (SURVEY 8d input 2): a short seeded sequence tiled to the batch size
+    base = synth.sequence(1235 + rank, min(B, 32), H, W)
+    frames = np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B]
+    dev = torch.device("cuda", local_rank)
+    d_imgs = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
+    d_kp = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    n_pairs = B - 1
+    d_to = torch.arange(1, B, dtype=torch.int32, device=dev)
+    d_from = torch.arange(0, B - 1, dtype=torch.int32, device=dev)
+    d_match = torch.zeros((max(n_pairs, 1), cap), dtype=torch.int32, device=dev)
+    d_dist = torch.zeros((max(n_pairs, 1), cap), dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(max(n_pairs, 1), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def check(rc):
+        if rc != 0:
+            raise RuntimeError(lib.orbgpu_last_error(fe.handle).decode())
+
+    stage_acc = np.zeros(7)
+    match_ms_acc = [0.0]
+
+    def step(record):
+        check(lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr(), W * H, W, B, NF, d_kp.data_ptr(),
+                                              d_desc.data_ptr(), cap, d_n.data_ptr()))
+        if record:
+            st = fe.stage_times()
+            stage_acc[:] += [st[k] for k in ("pyramid", "fast_score", "cells", "quadtree", "blur", "orient_describe", "total")]
+        t0 = time.perf_counter()
+        if n_pairs > 0:
+            check(lib.orbgpu_match_frames_device(fe.handle, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                                                 d_to.data_ptr(), d_from.data_ptr(), n_pairs, 100, 50, 0.9, 1,
+                                                 d_match.data_ptr(), d_dist.data_ptr(), d_nm.data_ptr()))
+        check(lib.orbgpu_synchronize(fe.handle))
+        if record:
+            match_ms_acc[0] += (time.perf_counter() - t0) * 1e3
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_kp = d_n.cpu().numpy()
+    n_matches = d_nm.cpu().numpy()[:n_pairs]
+    st = stage_acc / max(args.steps, 1)
+    # ---- roofline of the dominant extraction kernel (FAST score map, one launch per batch) --------------
+    # algorithmic bytes per launch = P bytes read per frame (SURVEY 8d "FAST (P read)") x frames per launch
+    fast_s = st[1] * 1e-3
+    hbm_peak = 8000.0
+    fast_gbs = P * B / fast_s / 1e9 if fast_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_fast_score", "achieved": round(fast_gbs, 2), "peak": hbm_peak,
+                "unit": "GB/s", "frac": round(fast_gbs / hbm_peak, 5), "traffic": None,
+                "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P * B}
+    # whole extraction against SURVEY 8d's per-frame figure A = 5P - px0 - px7 + 1978 N
+    A = 5 * P - g.w[0] * g.h[0] - g.w[g.levels - 1] * g.h[g.levels - 1] + 1978 * NF
+    ext_s = st[6] * 1e-3
+    pipeline = {"algorithmic_bytes_per_frame": A, "extract_ms_per_batch": round(st[6], 3),
+                "achieved_GBps": round(A * B / ext_s / 1e9, 2) if ext_s > 0 else 0.0,
+                "frac_of_8TBps": round(A * B / ext_s / 1e9 / hbm_peak, 5) if ext_s > 0 else 0.0,
+                "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast_score", "cells", "quadtree_host", "blur", "orient_describe"), st[:6])},
+                "link_match_ms_per_batch": round(match_ms_acc[0] / max(args.steps, 1), 3)}
+
+    matching = {}
+    if not args.no_bruteforce:
+        # BASELINE.json configs[3]: 100k x 100k brute-force SNN, reported beside the measured popcount ceiling
+        n = 100_000
+        frm = synth.descriptors(1237, n)
+        to = synth.descriptors(1238, n, planted_from=frm[:2000], planted_frac=0.3)
+        dt, df = torch.from_numpy(to).to(dev), torch.from_numpy(frm).to(dev)
+        di = torch.zeros(n, dtype=torch.int32, device=dev)
+        dd = torch.zeros(n, dtype=torch.int32, device=dev)
+        times = []
+        for it in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            check(lib.orbgpu_match_bruteforce_device(fe.handle, dt.data_ptr(), n, df.data_ptr(), n, 50, 0.9,
+                                                     di.data_ptr(), dd.data_ptr()))
+            check(lib.orbgpu_synchronize(fe.handle))
+            times.append(time.perf_counter() - t1)
+        bf = min(times[1:])
+        peak_measured = fe.popcount_peak()
+        nominal = 256 * 128 * 2.4e9 / 16  # CUs x lanes/clk x clock / 16 lane-ops per pair
+        matching = {"bruteforce_100k_pairs_per_s": round(n * n / bf, 1), "bruteforce_ms": round(bf * 1e3, 3),
+                    "popcount_peak_measured_pairs_per_s": round(peak_measured, 1),
+                    "popcount_peak_nominal_pairs_per_s": nominal,
+                    "frac_of_measured_peak": round(n * n / bf / peak_measured, 4),
+                    "frac_of_nominal_peak": round(n * n / bf / nominal, 4),
+                    "n_matched": int((di >= 0).sum().item())}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the oracle (CPU restatement; kind "port") on a bounded sample of the same frames, one core
+        from oracle import orb_oracle as oo
+        oo.build()
+        p = oo.params(W, H)
+        t1 = time.perf_counter()
+        done = 0
+        prev = None
+        budget_s = 12.0
+        while done < B and time.perf_counter() - t1 < budget_s:
+            k, d = oo.extract_literal(p, frames[done], NF)
+            if prev is not None:
+                mf, _ = oo.match_area(k, d, prev[0], prev[1], 100, 50, 0.9)
+                oo.orientation_validate(k["angle"], prev[0]["angle"], mf)
+            prev = (k, d)
+            done += 1
+        cpu_s = time.perf_counter() - t1
+        cpu = {"value": round(done / cpu_s, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"first {done} frames of the same {B}-frame batch: oracle extract (literal cv::FAST) + window link + rotation filter, single thread"}
+
+    out = {"metric": "frames/sec ORB extract+match (640x480, 8 lvls, 1000 kp); Hamming matches/sec",
+           "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8", "data": "synthetic",
+           "config": {"workload": f"synthetic {W}x{H} frame batch ({B} frames per GPU), 8 levels, {NF} keypoints, extract + window link match (BASELINE.json configs[1])",
+                      "frames_per_gpu": B, "keypoints_mean": round(float(n_kp.mean()), 1),
+                      "link_matches_mean": round(float(n_matches.mean()), 1) if n_pairs else 0.0,
+                      "parallelism": f"frame-sharded x{world}"},
+           "roofline": roofline, "pipeline": pipeline, "matching": matching, "cpu_baseline": cpu}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

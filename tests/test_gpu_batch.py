@@ -1,0 +1,76 @@
+"""GPU tests of the device-resident batch entry points used by bench.py: orbgpu_extract_batch_device and
+orbgpu_match_frames_device, checked per frame / per pair against the CPU oracle."""
+import numpy as np
+import pytest
+
+from orb_slam3_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_device_extract_and_link(oracle):
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    W, H, NF, B = 320, 240, 400, 6
+    frames = synth.sequence(77, B, H, W)
+    fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_batch=B, max_features=NF)
+    cap = fe.geometry(NF).keypoint_capacity
+    dev = torch.device("cuda", 0)
+    d_imgs = torch.from_numpy(frames).to(dev)
+    d_kp = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    rc = lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr(), W * H, W, B, NF, d_kp.data_ptr(),
+                                         d_desc.data_ptr(), cap, d_n.data_ptr())
+    assert rc == 0, lib.orbgpu_last_error(fe.handle)
+    to = torch.tensor([1, 2, 3, 4, 5, 0], dtype=torch.int32, device=dev)
+    frm = torch.tensor([0, 1, 2, 3, 4, 5], dtype=torch.int32, device=dev)
+    npairs = 6
+    d_m = torch.zeros((npairs, cap), dtype=torch.int32, device=dev)
+    d_d = torch.zeros((npairs, cap), dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(npairs, dtype=torch.int32, device=dev)
+    for check_orientation in (0, 1):
+        rc = lib.orbgpu_match_frames_device(fe.handle, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                                            to.data_ptr(), frm.data_ptr(), npairs, 100, 50, 0.9, check_orientation,
+                                            d_m.data_ptr(), d_d.data_ptr(), d_nm.data_ptr())
+        assert rc == 0, lib.orbgpu_last_error(fe.handle)
+        assert lib.orbgpu_synchronize(fe.handle) == 0
+        n = d_n.cpu().numpy()
+        kp = d_kp.cpu().numpy().view(_lib.KP_DTYPE).reshape(B, cap)
+        desc = d_desc.cpu().numpy()
+        m = d_m.cpu().numpy()
+        nm = d_nm.cpu().numpy()
+        p = oracle.params(W, H)
+        ok = [oracle.extract(p, frames[f], NF) for f in range(B)]
+        for f in range(B):
+            k, d = ok[f]
+            assert n[f] == len(k)
+            assert np.array_equal(kp[f, :n[f]]["x"], k["x"]) and np.array_equal(kp[f, :n[f]]["y"], k["y"])
+            assert np.array_equal(kp[f, :n[f]]["level"], k["level"])
+            assert np.array_equal(kp[f, :n[f]]["angle"], k["angle"].astype(np.float32))
+            assert np.array_equal(desc[f, :n[f]], d)
+        for pi, (t, fr) in enumerate(zip(to.cpu().numpy(), frm.cpu().numpy())):
+            mf, _ = oracle.match_area(ok[t][0], ok[t][1], ok[fr][0], ok[fr][1], 100, 50, 0.9)
+            if check_orientation:
+                mf, _ = oracle.orientation_validate(ok[t][0]["angle"], ok[fr][0]["angle"], mf)
+            assert np.array_equal(m[pi, :n[t]], mf), f"pair {pi}"
+            assert nm[pi] == (mf >= 0).sum()
+    fe.close()
+
+
+def test_error_behaviour():
+    from orb_slam3_amd._lib import OrbGpuError
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    fe = ORBFeatureExtractor(160, 120, 1.2, 3, 20, 7, max_features=100)
+    ft = Features(160, 120)
+    assert fe.Extract(np.zeros((0, 0), np.uint8), ft, 100) == -1          # empty image -> -1 like the reference
+    assert fe.Extract(np.full((120, 160), 90, np.uint8), ft, 100) == 0 and ft.Size() == 0  # flat image: no corners
+    with pytest.raises(OrbGpuError):
+        fe.Extract(np.zeros((100, 100), np.uint8), ft, 100)                # wrong size
+    with pytest.raises(OrbGpuError):
+        fe.Extract(np.zeros((120, 160), np.uint8), ft, 5000)               # above max_features
+    fe.close()
+    with pytest.raises(OrbGpuError):
+        ORBFeatureExtractor(64, 64, 1.2, 8, 20, 7)                          # top levels smaller than a FAST cell
