@@ -1,0 +1,143 @@
+// GPU-backed bodies for the reference's matcher entry points.
+//
+// SNNMatcher<It>::MatchWithIterators (src/features/matching/second_nearest_neighbor_matcher.hpp:30-80) is a
+// header-only template, not a virtual seam, so the replacement keeps the call shape of its three users and gathers
+// (descriptor, position, radius, level-range) arrays for ONE batched C-ABI call:
+//   * MatchArea       <- SNNMatcher<AreaToIterator>          (frame/monocular/monocular_frame.cpp:173-184)
+//   * MatchProjection <- SNNMatcher<ProjectionSearchIterator> (monocular_frame.cpp:285-306, monocular_key_frame.cpp:183-216,353-376)
+//   * HipOrientationValidator::Validate <- OrientationValidator::Validate (validators/orientation_validator.cpp:16-40)
+// Compiled inside the reference tree (includes its headers).  Results are the same unordered maps.
+#ifndef ORB_SLAM3_AMD_HIP_SNN_MATCHER_H_
+#define ORB_SLAM3_AMD_HIP_SNN_MATCHER_H_
+
+#include <algorithm>
+#include <list>
+#include <stdexcept>
+#include <unordered_map>
+#include <vector>
+
+#include <features/features.h>                    // reference headers
+#include <frame/map_point_visibility_params.h>
+#include <map/map_point.h>
+#include "orbgpu.h"
+
+namespace orb_slam3 {
+namespace features {
+namespace matching {
+
+class HipSNNMatcher {
+ public:
+  // same arguments as SNNMatcher(nearest_neighbour_ratio, threshold), second_nearest_neighbor_matcher.hpp:26-28
+  HipSNNMatcher(orbgpu_ctx * ctx, precision_t nearest_neighbour_ratio, unsigned threshold)
+      : ctx_(ctx), nearest_neighbour_ratio_(nearest_neighbour_ratio), THRESHOLD_(threshold) {}
+
+  // AreaToIterator(0 .. Size(), to, from, window_size): level-0 window search on both sides; id 0 is visited
+  // whatever its level (iterators/area_to_iterator.h:24-43, area_to_pointee.h:43-54)
+  void MatchArea(const Features & to, const Features & from, size_t window_size,
+                 std::unordered_map<std::size_t, std::size_t> & out_matches) const {
+    const size_t nt = to.Size(), nf = from.Size();
+    std::vector<double> to_xy(2 * nt), from_xy(2 * nf);
+    std::vector<uint64_t> win(nt, (uint64_t)window_size);
+    std::vector<int32_t> lmin(nt, 0), lmax(nt, 0), flev(nf);
+    std::vector<uint8_t> active(nt);
+    for (size_t i = 0; i < nt; ++i) {
+      to_xy[2 * i] = to.keypoints[i].X();
+      to_xy[2 * i + 1] = to.keypoints[i].Y();
+      active[i] = (i == 0) || (to.keypoints[i].level == 0);
+    }
+    Fill(from, from_xy, flev);
+    Run(to.descriptors.data(), nt, to_xy, win, lmin, lmax, &active, from, from_xy, flev,
+        [&](size_t i, size_t j) { out_matches[i] = j; });
+  }
+
+  // ProjectionSearchIterator(begin, end, from_features): 'to' = visible map points
+  // (iterators/projection_search_pointee.cpp:20-35); window_size is truncated by the const size_t& parameter of
+  // ListFeaturesInArea (features.cpp:82); levels [max(l-1,0), l+1]
+  void MatchProjection(const std::list<frame::MapPointVisibilityParams> & visibles, const Features & from,
+                       std::unordered_map<map::MapPoint *, std::size_t> & out_matches) const {
+    const size_t nt = visibles.size(), nf = from.Size();
+    std::vector<uint8_t> to_desc(32 * nt);
+    std::vector<double> to_xy(2 * nt), from_xy(2 * nf);
+    std::vector<uint64_t> win(nt);
+    std::vector<int32_t> lmin(nt), lmax(nt), flev(nf);
+    std::vector<map::MapPoint *> ids(nt);
+    size_t i = 0;
+    for (const auto & v : visibles) {
+      const DescriptorType d = v.map_point->GetDescriptor();
+      std::copy(d.data(), d.data() + 32, to_desc.begin() + 32 * i);
+      to_xy[2 * i] = v.position.x();
+      to_xy[2 * i + 1] = v.position.y();
+      win[i] = (uint64_t)(size_t)v.window_size;
+      lmin[i] = std::max(v.level - 1, 0);
+      lmax[i] = v.level + 1;
+      ids[i] = v.map_point;
+      ++i;
+    }
+    Fill(from, from_xy, flev);
+    Run(to_desc.data(), nt, to_xy, win, lmin, lmax, nullptr, from, from_xy, flev,
+        [&](size_t a, size_t j) { out_matches[ids[a]] = j; });
+  }
+
+ private:
+  static void Fill(const Features & from, std::vector<double> & xy, std::vector<int32_t> & lev) {
+    for (size_t j = 0; j < from.Size(); ++j) {
+      xy[2 * j] = from.keypoints[j].X();      // distorted keypoints, features.cpp:104
+      xy[2 * j + 1] = from.keypoints[j].Y();
+      lev[j] = from.keypoints[j].level;
+    }
+  }
+  template <class Emit>
+  void Run(const uint8_t * to_desc, size_t nt, const std::vector<double> & to_xy, const std::vector<uint64_t> & win,
+           const std::vector<int32_t> & lmin, const std::vector<int32_t> & lmax, const std::vector<uint8_t> * active,
+           const Features & from, const std::vector<double> & from_xy, const std::vector<int32_t> & flev,
+           Emit emit) const {
+    if (nt == 0) return;
+    orbgpu_window_args a{};
+    a.to_desc = to_desc; a.to_xy = to_xy.data(); a.to_window = win.data();
+    a.to_min_level = lmin.data(); a.to_max_level = lmax.data(); a.to_active = active ? active->data() : nullptr;
+    a.n_to = (int32_t)nt;
+    a.from_desc = from.descriptors.data(); a.from_xy = from_xy.data(); a.from_level = flev.data();
+    a.n_from = (int32_t)from.Size();
+    a.threshold = THRESHOLD_; a.ratio = nearest_neighbour_ratio_;
+    std::vector<int32_t> idx(nt);
+    std::vector<uint32_t> dist(nt);
+    if (orbgpu_match_window(ctx_, &a, idx.data(), dist.data()) != ORBGPU_OK)
+      throw std::runtime_error(std::string("orbgpu_match_window: ") + orbgpu_last_error(ctx_));
+    for (size_t i = 0; i < nt; ++i)
+      if (idx[i] >= 0) emit(i, (size_t)idx[i]);
+  }
+  orbgpu_ctx * ctx_;
+  const precision_t nearest_neighbour_ratio_;
+  const unsigned THRESHOLD_;
+};
+
+class HipOrientationValidator {
+ public:
+  HipOrientationValidator(orbgpu_ctx * ctx, const std::vector<KeyPoint> & kp_to, const std::vector<KeyPoint> & kp_from)
+      : ctx_(ctx), kp_to_(&kp_to), kp_from_(&kp_from) {}
+  // validators/orientation_validator.cpp:16-40: erases the matches outside the top-3 rotation bins, returns how many
+  int Validate(std::unordered_map<std::size_t, std::size_t> & inout_matches_12) const {
+    const size_t nt = kp_to_->size(), nf = kp_from_->size();
+    if (nt == 0) return 0;
+    std::vector<float> a_to(nt), a_from(nf);
+    for (size_t i = 0; i < nt; ++i) a_to[i] = (float)(*kp_to_)[i].angle;      // angles hold float values
+    for (size_t j = 0; j < nf; ++j) a_from[j] = (float)(*kp_from_)[j].angle;
+    std::vector<int32_t> m(nt, -1);
+    for (const auto & kv : inout_matches_12) m[kv.first] = (int32_t)kv.second;
+    int32_t nd = 0;
+    if (orbgpu_rotation_filter(ctx_, a_to.data(), (int32_t)nt, a_from.data(), (int32_t)nf, m.data(), &nd) != ORBGPU_OK)
+      throw std::runtime_error(std::string("orbgpu_rotation_filter: ") + orbgpu_last_error(ctx_));
+    for (auto it = inout_matches_12.begin(); it != inout_matches_12.end();)
+      it = (m[it->first] < 0) ? inout_matches_12.erase(it) : std::next(it);
+    return nd;
+  }
+ private:
+  orbgpu_ctx * ctx_;
+  const std::vector<KeyPoint> * kp_to_;
+  const std::vector<KeyPoint> * kp_from_;
+};
+
+}  // namespace matching
+}  // namespace features
+}  // namespace orb_slam3
+#endif

@@ -1,0 +1,73 @@
+// Drives the C++ adapters (orb_slam3_amd/host/) the way the reference's callers do and dumps the results for
+// tests/test_gpu_host_adapter.py to compare with the oracle.  usage: adapter_test W H NFEAT img0.raw img1.raw out.bin
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+#include <list>
+#include <memory>
+
+#include "hip_orb_feature_extractor.h"
+#include "hip_snn_matcher.h"
+
+using namespace orb_slam3;
+
+static TImageGray8U load(const char * path, int w, int h) {
+  TImageGray8U img;
+  img.resize(h, w);
+  std::ifstream f(path, std::ios::binary);
+  f.read((char *)img.data(), (std::streamsize)w * h);
+  return img;
+}
+
+template <class T>
+static void put(std::ofstream & o, const T & v) { o.write((const char *)&v, sizeof(T)); }
+
+int main(int argc, char ** argv) {
+  if (argc != 7) return 2;
+  const int w = atoi(argv[1]), h = atoi(argv[2]), nfeat = atoi(argv[3]);
+  // the driver's construction, main.cpp:451-454, through the interface pointer Atlas owns (map/atlas.h:44)
+  std::unique_ptr<features::IFeatureExtractor> fe(new features::HipORBFeatureExtractor(w, h, 1.2, 8, 20, 7, 0, nfeat));
+  auto * hip = static_cast<features::HipORBFeatureExtractor *>(fe.get());
+  features::Features f0(w, h), f1(w, h);
+  TImageGray8U i0 = load(argv[4], w, h), i1 = load(argv[5], w, h), empty;
+  if (fe->Extract(empty, f0, nfeat) != -1) return 3;  // orb_feature_extractor.cpp:533
+  if (fe->Extract(i0, f0, nfeat) != 0 || fe->Extract(i1, f1, nfeat) != 0) return 4;
+  // MonocularFrame::ComputeMatchesForLinking, monocular_frame.cpp:173-189
+  std::unordered_map<std::size_t, std::size_t> matches;
+  features::matching::HipSNNMatcher matcher(hip->context(), 0.9, 50);
+  matcher.MatchArea(f1, f0, 100, matches);
+  const size_t n_before = matches.size();
+  const int discarded = features::matching::HipOrientationValidator(hip->context(), f1.keypoints, f0.keypoints).Validate(matches);
+  // SearchInVisiblePoints, monocular_frame.cpp:285-306: one "map point" per level-0/1 keypoint of frame 0
+  std::vector<map::MapPoint> mps(f0.Size());
+  std::list<frame::MapPointVisibilityParams> vis;
+  for (size_t j = 0; j < f0.Size(); ++j) {
+    if (f0.keypoints[j].level > 1) continue;
+    std::memcpy(mps[j].desc.d, f0.descriptors.data() + 32 * j, 32);
+    frame::MapPointVisibilityParams v{};
+    v.map_point = &mps[j];
+    v.window_size = 15.7 * fe->GetScaleFactors()[(size_t)f0.keypoints[j].level];
+    v.position = f0.keypoints[j].pt;
+    v.level = f0.keypoints[j].level;
+    vis.push_back(v);
+  }
+  std::unordered_map<map::MapPoint *, std::size_t> proj;
+  features::matching::HipSNNMatcher(hip->context(), 0.9, 100).MatchProjection(vis, f1, proj);
+
+  std::ofstream o(argv[6], std::ios::binary);
+  for (const features::Features * f : {&f0, &f1}) {
+    put(o, (int32_t)f->Size());
+    for (const auto & k : f->keypoints) { put(o, k.pt[0]); put(o, k.pt[1]); put(o, k.angle); put(o, k.size); put(o, (int32_t)k.level); }
+    o.write((const char *)f->descriptors.data(), (std::streamsize)f->Size() * 32);
+  }
+  put(o, (int32_t)n_before); put(o, (int32_t)discarded); put(o, (int32_t)matches.size());
+  for (const auto & kv : matches) { put(o, (int32_t)kv.first); put(o, (int32_t)kv.second); }
+  put(o, (int32_t)proj.size());
+  for (const auto & kv : proj) { put(o, (int32_t)(kv.first - mps.data())); put(o, (int32_t)kv.second); }
+  // scalar helpers
+  put(o, (uint32_t)fe->PredictScale(1.0, 3.0)); put(o, fe->GetAcceptableSquareError(3));
+  features::DescriptorType a, b; std::memcpy(a.d, f0.descriptors.data(), 32); std::memcpy(b.d, f0.descriptors.data() + 32, 32);
+  put(o, (uint32_t)fe->ComputeDistance(a, b));
+  std::ostringstream ss; fe->Serialize(ss); put(o, (int32_t)ss.str().size());
+  return 0;
+}
