@@ -159,7 +159,7 @@ def main():
             times.append(time.perf_counter() - t1)
         bf = min(times[1:])
         peak_measured = fe.popcount_peak()
-        nominal = 256 * 128 * 2.4e9 / 16  # CUs x lanes/clk x clock / 16 lane-ops per pair
+        nominal = 256 * 64 * 2.4e9 / 16  # CUs x 64 int lanes/clk x 2.4 GHz / 16 lane-ops per pair
         matching = {"bruteforce_100k_pairs_per_s": round(n * n / bf, 1), "bruteforce_ms": round(bf * 1e3, 3),
                     "popcount_peak_measured_pairs_per_s": round(peak_measured, 1),
                     "popcount_peak_nominal_pairs_per_s": nominal,

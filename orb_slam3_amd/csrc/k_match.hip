@@ -25,69 +25,122 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
   return r;
 }
 
-struct ToLane {
-  unsigned d[8];
+// popcount-accumulate: v_bcnt_u32_b32 d, x, acc  (d = popcount(x) + acc).  Written as asm so that the compiler
+// keeps the 8-deep accumulate chain (16 lane-ops per pair) instead of re-associating it into bcnt + add3 trees.
+__device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc) {
+  unsigned r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+
+__device__ __forceinline__ unsigned hamming8(const unsigned (&t)[8], const uint4 &a, const uint4 &b) {
+  unsigned d = __builtin_popcount(t[0] ^ a.x);
+  d = bcnt_acc(t[1] ^ a.y, d);
+  d = bcnt_acc(t[2] ^ a.z, d);
+  d = bcnt_acc(t[3] ^ a.w, d);
+  d = bcnt_acc(t[4] ^ b.x, d);
+  d = bcnt_acc(t[5] ^ b.y, d);
+  d = bcnt_acc(t[6] ^ b.z, d);
+  d = bcnt_acc(t[7] ^ b.w, d);
+  return d;
+}
+
+struct ToWindow {
   double x, y, win;
   int lmin, lmax;
   bool check_levels;
 };
 
-// scan 'from' rows [j0, j1) for one lane's 'to'; best/second are packed keys (best <= second)
-template <bool WINDOW>
-__device__ __forceinline__ void snn_scan(const ToLane &t, const uint4 *__restrict__ from_desc,
-                                         const double2 *__restrict__ from_xy, const int *__restrict__ from_level,
-                                         int j0, int j1, unsigned &best, unsigned &second) {
-#pragma unroll 4
-  for (int j = j0; j < j1; j++) {
-    const uint4 a = from_desc[2 * j], b = from_desc[2 * j + 1];
-    unsigned d = __builtin_popcount(t.d[0] ^ a.x);
-    d += __builtin_popcount(t.d[1] ^ a.y);
-    d += __builtin_popcount(t.d[2] ^ a.z);
-    d += __builtin_popcount(t.d[3] ^ a.w);
-    d += __builtin_popcount(t.d[4] ^ b.x);
-    d += __builtin_popcount(t.d[5] ^ b.y);
-    d += __builtin_popcount(t.d[6] ^ b.z);
-    d += __builtin_popcount(t.d[7] ^ b.w);
-    unsigned key = (d << IDX_BITS) | (unsigned)j;
-    if (WINDOW) {
-      const double2 p = from_xy[j];
-      const int lv = from_level[j];
-      // features.cpp:109-119: level rule, then strict |dx| < r and |dy| < r in double
-      bool ok = fabs(p.x - t.x) < t.win && fabs(p.y - t.y) < t.win;
-      if (t.check_levels) ok = ok && lv >= t.lmin && !(t.lmax >= 0 && lv > t.lmax);
-      key = ok ? key : KEY_NONE;
-    }
-    second = umed3(best, key, second);  // = min(second, max(best, key)) because best <= second
-    best = min(best, key);
-  }
+// features.cpp:109-119: level rule, then strict |dx| < r and |dy| < r in double
+__device__ __forceinline__ bool window_ok(const ToWindow &t, const double2 p, int lv) {
+  bool ok = fabs(p.x - t.x) < t.win && fabs(p.y - t.y) < t.win;
+  if (t.check_levels) ok = ok && lv >= t.lmin && !(t.lmax >= 0 && lv > t.lmax);
+  return ok;
 }
 
-// grid: x = 'to' blocks of 256 lanes, y = 'from' chunks.  partial[chunk][n_to] = (best, second)
-template <bool WINDOW>
+constexpr int SNN_U = 4;  // 'from' rows fetched per scalar-load group
+
+// grid: x = 'to' blocks of 256*T rows (T rows per lane, 256 apart), y = 'from' chunks.
+// partial[chunk][n_to] = (best, second) packed keys.  The 'from' rows of the next group are fetched (scalar
+// loads, wave-uniform) while the current group is being evaluated.
+template <bool WINDOW, int T>
 __global__ __launch_bounds__(256) void k_snn_partial(orbgpu_window_args a, int chunk, uint2 *__restrict__ partial) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
   const int j0 = blockIdx.y * chunk, j1 = min(j0 + chunk, a.n_from);
-  ToLane t;
-  const int ii = min(i, a.n_to - 1);
-  const uint4 *td = reinterpret_cast<const uint4 *>(a.to_desc) + 2 * (size_t)ii;
-  const uint4 t0 = td[0], t1 = td[1];
-  t.d[0] = t0.x; t.d[1] = t0.y; t.d[2] = t0.z; t.d[3] = t0.w;
-  t.d[4] = t1.x; t.d[5] = t1.y; t.d[6] = t1.z; t.d[7] = t1.w;
-  t.x = t.y = t.win = 0;
-  t.lmin = t.lmax = 0;
-  t.check_levels = false;
-  if (WINDOW) {
-    t.x = a.to_xy[2 * ii];
-    t.y = a.to_xy[2 * ii + 1];
-    t.win = (double)a.to_window[ii];
-    t.lmin = a.to_min_level[ii];
-    t.lmax = a.to_max_level[ii];
-    t.check_levels = (t.lmin > 0) || (t.lmax >= 0);  // features.cpp:94
+  const uint4 *__restrict__ fd = reinterpret_cast<const uint4 *>(a.from_desc);
+  const double2 *__restrict__ fxy = reinterpret_cast<const double2 *>(a.from_xy);
+  const int *__restrict__ flv = a.from_level;
+  unsigned t[T][8];
+  ToWindow tw[T];
+  int row[T];
+#pragma unroll
+  for (int q = 0; q < T; q++) {
+    row[q] = blockIdx.x * (256 * T) + q * 256 + threadIdx.x;
+    const int ii = min(row[q], a.n_to - 1);
+    const uint4 *td = reinterpret_cast<const uint4 *>(a.to_desc) + 2 * (size_t)ii;
+    const uint4 t0 = td[0], t1 = td[1];
+    t[q][0] = t0.x; t[q][1] = t0.y; t[q][2] = t0.z; t[q][3] = t0.w;
+    t[q][4] = t1.x; t[q][5] = t1.y; t[q][6] = t1.z; t[q][7] = t1.w;
+    if (WINDOW) {
+      tw[q].x = a.to_xy[2 * ii];
+      tw[q].y = a.to_xy[2 * ii + 1];
+      tw[q].win = (double)a.to_window[ii];
+      tw[q].lmin = a.to_min_level[ii];
+      tw[q].lmax = a.to_max_level[ii];
+      tw[q].check_levels = (tw[q].lmin > 0) || (tw[q].lmax >= 0);  // features.cpp:94
+    }
   }
-  unsigned best = KEY_NONE, second = KEY_NONE;
-  snn_scan<WINDOW>(t, reinterpret_cast<const uint4 *>(a.from_desc), reinterpret_cast<const double2 *>(a.from_xy),
-                   a.from_level, j0, j1, best, second);
-  if (i < a.n_to) partial[(size_t)blockIdx.y * a.n_to + i] = make_uint2(best, second);
+  unsigned best[T], second[T];
+#pragma unroll
+  for (int q = 0; q < T; q++) best[q] = second[q] = KEY_NONE;
+
+  auto eval = [&](int j, const uint4 &fa, const uint4 &fb) {
+    double2 p = make_double2(0, 0);
+    int lv = 0;
+    if (WINDOW) {
+      p = fxy[j];
+      lv = flv[j];
+    }
+#pragma unroll
+    for (int q = 0; q < T; q++) {
+      const unsigned d = hamming8(t[q], fa, fb);
+      unsigned key = (d << IDX_BITS) | (unsigned)j;
+      if (WINDOW) key = window_ok(tw[q], p, lv) ? key : KEY_NONE;
+      second[q] = umed3(best[q], key, second[q]);  // = min(second, max(best, key)) because best <= second
+      best[q] = min(best[q], key);
+    }
+  };
+
+  int j = j0;
+  const int jfull = j0 + ((j1 - j0) / SNN_U) * SNN_U;
+  if (j < jfull) {
+    uint4 ca[SNN_U], cb[SNN_U];
+#pragma unroll
+    for (int u = 0; u < SNN_U; u++) {
+      ca[u] = fd[2 * (j + u)];
+      cb[u] = fd[2 * (j + u) + 1];
+    }
+    for (; j < jfull; j += SNN_U) {
+      uint4 na[SNN_U], nb[SNN_U];
+      const int jn = min(j + SNN_U, jfull - SNN_U);  // last iteration re-fetches its own group
+#pragma unroll
+      for (int u = 0; u < SNN_U; u++) {
+        na[u] = fd[2 * (jn + u)];
+        nb[u] = fd[2 * (jn + u) + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < SNN_U; u++) eval(j + u, ca[u], cb[u]);
+#pragma unroll
+      for (int u = 0; u < SNN_U; u++) {
+        ca[u] = na[u];
+        cb[u] = nb[u];
+      }
+    }
+  }
+  for (; j < j1; j++) eval(j, fd[2 * j], fd[2 * j + 1]);
+
+#pragma unroll
+  for (int q = 0; q < T; q++)
+    if (row[q] < a.n_to) partial[(size_t)blockIdx.y * a.n_to + row[q]] = make_uint2(best[q], second[q]);
 }
 
 __device__ __forceinline__ void merge_keys(unsigned &best, unsigned &second, unsigned b2, unsigned s2) {
@@ -328,22 +381,21 @@ __global__ __launch_bounds__(256) void k_popcount_peak(unsigned *sink, int iters
   unsigned t[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) t[k] = (threadIdx.x + 1) * 2654435761u + k * 40503u + blockIdx.x;
-  unsigned acc = 0xffffffffu;
+  unsigned acc0 = 0, acc1 = 0;
   unsigned s = blockIdx.x * 7u + 1u;
-#pragma unroll 8
-  for (int it = 0; it < iters; it++) {
-    s = s * 1664525u + 1013904223u;  // scalar LCG: wave-uniform 'from' words
-    unsigned d = __builtin_popcount(t[0] ^ s);
-    d += __builtin_popcount(t[1] ^ (s + 0x9e3779b9u));
-    d += __builtin_popcount(t[2] ^ (s + 0x3c6ef372u));
-    d += __builtin_popcount(t[3] ^ (s + 0xdaa66d2bu));
-    d += __builtin_popcount(t[4] ^ (s + 0x78dde6e4u));
-    d += __builtin_popcount(t[5] ^ (s + 0x1715609du));
-    d += __builtin_popcount(t[6] ^ (s + 0xb54cda56u));
-    d += __builtin_popcount(t[7] ^ (s + 0x5384540fu));
-    acc = min(acc, d);
+#pragma unroll 1
+  for (int it = 0; it < iters; it += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      s = s * 1664525u + 1013904223u;  // scalar LCG: wave-uniform 'from' words (stay in SGPRs)
+      uint4 a = make_uint4(s, s + 0x9e3779b9u, s + 0x3c6ef372u, s + 0xdaa66d2bu);
+      uint4 b = make_uint4(s + 0x78dde6e4u, s + 0x1715609du, s + 0xb54cda56u, s + 0x5384540fu);
+      unsigned d = hamming8(t, a, b);
+      asm volatile("" : "+v"(d));  // the pair's distance must exist in a VGPR
+      if (u & 1) acc1 ^= d; else acc0 ^= d;
+    }
   }
-  if (acc == 0x12345u) sink[0] = acc;  // never true: keeps the loop alive
+  if ((acc0 ^ acc1) == 0x12345u) sink[0] = acc0;
 }
 
 }  // namespace
@@ -372,11 +424,16 @@ void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a, int *d_from_
   uint2 *partial = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(scratch) +
                                              (((size_t)a.n_from * sizeof(unsigned long long) + 255) & ~(size_t)255));
   (void)hipMemsetAsync(claim, 0xff, (size_t)a.n_from * sizeof(unsigned long long), c->stream);
-  dim3 grid((a.n_to + 255) / 256, n_chunks);
-  if (a.to_xy)
-    hipLaunchKernelGGL(k_snn_partial<true>, grid, dim3(256), 0, c->stream, a, chunk, partial);
-  else
-    hipLaunchKernelGGL(k_snn_partial<false>, grid, dim3(256), 0, c->stream, a, chunk, partial);
+  if (a.to_xy) {
+    dim3 grid((a.n_to + 255) / 256, n_chunks);
+    hipLaunchKernelGGL((k_snn_partial<true, 1>), grid, dim3(256), 0, c->stream, a, chunk, partial);
+  } else if (a.n_to >= 16384) {
+    dim3 grid((a.n_to + 511) / 512, n_chunks);
+    hipLaunchKernelGGL((k_snn_partial<false, 2>), grid, dim3(256), 0, c->stream, a, chunk, partial);
+  } else {
+    dim3 grid((a.n_to + 255) / 256, n_chunks);
+    hipLaunchKernelGGL((k_snn_partial<false, 1>), grid, dim3(256), 0, c->stream, a, chunk, partial);
+  }
   const unsigned th = std::min(a.threshold, 256u);
   hipLaunchKernelGGL(k_snn_finalize, dim3((a.n_to + 255) / 256), dim3(256), 0, c->stream, partial, n_chunks, a.n_to,
                      a.to_active, th, a.ratio, d_from_idx, d_dist, claim);
@@ -412,7 +469,7 @@ void launch_rotation_filter(const orbgpu_ctx *c, const float *d_ang_to, int n_to
 
 double run_popcount_peak(const orbgpu_ctx *c) {
   unsigned *sink = reinterpret_cast<unsigned *>(c->d_match_scratch);
-  const int iters = 1 << 16;
+  const int iters = 1 << 15;
   const int blocks = 256 * 8;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
