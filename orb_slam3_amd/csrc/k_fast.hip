@@ -47,11 +47,33 @@ __device__ __forceinline__ int fast_score16(int v, const int (&r)[16], int min_t
 }
 
 // One launch covers all levels of all frames: blockIdx.x = tile over (level, ty, tx), blockIdx.y = frame.
-// Tile 128 x 16 output pixels, staged with a 3-row / 4-column apron as dwords; each thread scores
-// 4 adjacent pixels of 2 rows from 3 dwords x 7 rows held in registers.
+// Tile 128 x 16 output pixels, staged with a 3-row / 4-column apron as dwords.
+//   phase 1: every lane runs the cheap opposite-pair test on 2 rows x 2 pixel PAIRS in packed u16 math
+//            (v_perm_b32 picks the two pixels' ring bytes, v_pk_min/max_u16 reduce them); ~13 % of the pixels of a
+//            textured frame survive and are pushed on an LDS queue;
+//   phase 2: the queue is drained densely: one lane per surviving pixel computes the full 9-arc score from the LDS tile;
+//   phase 3: the score tile is written back with coalesced dword stores.
+typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
+
+__device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+// bytes b and b+1 of the 12-byte window {w0,w1,w2} zero-extended into the two u16 halves
+template <int B>
+__device__ __forceinline__ u16x2 pair_bytes(const unsigned (&w)[3]) {
+  constexpr int lo = B >> 2;
+  constexpr int k0 = B & 3, k1 = k0 + 1;  // byte positions inside the 8-byte pool {w[lo+1], w[lo]}
+  constexpr unsigned sel = (unsigned)k0 | (0x0cu << 8) | ((unsigned)k1 << 16) | (0x0cu << 24);
+  const unsigned hi = (lo + 1 < 3) ? w[lo + 1 < 3 ? lo + 1 : 2] : 0u;
+  return as_u16x2(__builtin_amdgcn_perm(hi, w[lo], sel));
+}
+
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score,
                                                     DeviceGeom g) {
   __shared__ unsigned tile[(TILE_H + 6) * TILE_DW];
+  __shared__ unsigned out_tile[TILE_H * TILE_W / 4];
+  __shared__ unsigned short queue[TILE_H * TILE_W];
+  __shared__ int q_count;
   int t = blockIdx.x, l = 0;
 #pragma unroll 1
   while (l + 1 < g.levels && t >= g.lv[l + 1].tile_off) l++;
@@ -62,81 +84,151 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
   const size_t base = (size_t)blockIdx.y * g.frame_bytes + L.off;
   const uint8_t *src = pyr + base;
 
-  for (int i = threadIdx.x; i < (TILE_H + 6) * TILE_DW; i += 256) {
-    int r = i / TILE_DW, c = i - r * TILE_DW;
-    int gy = y0 - 3 + r, gx = x0 - 4 + 4 * c;
-    unsigned v = 0;
-    // pixels outside the image are never part of a scored ring (scores exist for [3,w-4]x[3,h-4] only)
-    if (gy >= 0 && gy < L.h && gx >= 0 && gx < L.pitch) v = *reinterpret_cast<const unsigned *>(src + (size_t)gy * L.pitch + gx);
-    tile[i] = v;
+  if (threadIdx.x == 0) q_count = 0;
+  out_tile[threadIdx.x] = 0;
+  out_tile[threadIdx.x + 256] = 0;
+  {
+    // 22 x 34 dwords; pixels outside the image are never part of a scored ring
+    unsigned v[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int i = threadIdx.x + 256 * k;
+      const int r = i / TILE_DW, c = i - r * TILE_DW;
+      const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * c;
+      v[k] = 0;
+      if (i < (TILE_H + 6) * TILE_DW && gy >= 0 && gy < L.h && gx >= 0 && gx < L.pitch)
+        v[k] = *reinterpret_cast<const unsigned *>(src + (size_t)gy * L.pitch + gx);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < (TILE_H + 6) * TILE_DW) tile[i] = v[k];
+    }
   }
   __syncthreads();
 
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int min_thr = g.fast_min;
-#pragma unroll 1
+  const u16x2 thr2 = {(unsigned short)min_thr, (unsigned short)min_thr};
+  // ---- phase 1: packed quick test -------------------------------------------------------------
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    const int ry = ty + 8 * half;
+    const int y = y0 + ry, x = x0 + 4 * tx;
+    if (y < 3 || y > L.h - 4) continue;
+    unsigned mask = 0;  // bit p: pixel x+p may be a corner
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+      // 12-byte windows (columns x-4 .. x+7) of the 7 rows y-3 .. y+3; pair = pixels x+2pr, x+2pr+1
+      unsigned w[7][3];
+#pragma unroll
+      for (int j = 0; j < 7; j++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) w[j][q] = tile[(ry + j) * TILE_DW + tx + q];
+      constexpr int dummy = 0;
+      (void)dummy;
+      u16x2 r[16];
+      // ring (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+      if (pr == 0) {
+        r[0] = pair_bytes<4>(w[6]);  r[1] = pair_bytes<5>(w[6]);  r[2] = pair_bytes<6>(w[5]);  r[3] = pair_bytes<7>(w[4]);
+        r[4] = pair_bytes<7>(w[3]);  r[5] = pair_bytes<7>(w[2]);  r[6] = pair_bytes<6>(w[1]);  r[7] = pair_bytes<5>(w[0]);
+        r[8] = pair_bytes<4>(w[0]);  r[9] = pair_bytes<3>(w[0]);  r[10] = pair_bytes<2>(w[1]); r[11] = pair_bytes<1>(w[2]);
+        r[12] = pair_bytes<1>(w[3]); r[13] = pair_bytes<1>(w[4]); r[14] = pair_bytes<2>(w[5]); r[15] = pair_bytes<3>(w[6]);
+      } else {
+        r[0] = pair_bytes<6>(w[6]);  r[1] = pair_bytes<7>(w[6]);  r[2] = pair_bytes<8>(w[5]);  r[3] = pair_bytes<9>(w[4]);
+        r[4] = pair_bytes<9>(w[3]);  r[5] = pair_bytes<9>(w[2]);  r[6] = pair_bytes<8>(w[1]);  r[7] = pair_bytes<7>(w[0]);
+        r[8] = pair_bytes<6>(w[0]);  r[9] = pair_bytes<5>(w[0]);  r[10] = pair_bytes<4>(w[1]); r[11] = pair_bytes<3>(w[2]);
+        r[12] = pair_bytes<3>(w[3]); r[13] = pair_bytes<3>(w[4]); r[14] = pair_bytes<4>(w[5]); r[15] = pair_bytes<5>(w[6]);
+      }
+      const u16x2 v = pr == 0 ? pair_bytes<4>(w[3]) : pair_bytes<6>(w[3]);
+      // dark 9-arc needs min(ring_k, ring_k+8) < v - t for all 8 opposite pairs, bright max(...) > v + t
+      u16x2 mx_of_min = __builtin_elementwise_min(r[0], r[8]);
+      u16x2 mn_of_max = __builtin_elementwise_max(r[0], r[8]);
+#pragma unroll
+      for (int k = 1; k < 8; k++) {
+        mx_of_min = __builtin_elementwise_max(mx_of_min, __builtin_elementwise_min(r[k], r[k + 8]));
+        mn_of_max = __builtin_elementwise_min(mn_of_max, __builtin_elementwise_max(r[k], r[k + 8]));
+      }
+      // all values are 0..255 (+t): plain u16 arithmetic cannot wrap
+      const u16x2 dark_lim = mx_of_min + thr2;   // candidate iff dark_lim < v
+      const u16x2 bright_lim = v + thr2;         // candidate iff bright_lim < mn_of_max
+      const unsigned c0 = (dark_lim.x < v.x) | (bright_lim.x < mn_of_max.x);
+      const unsigned c1 = (dark_lim.y < v.y) | (bright_lim.y < mn_of_max.y);
+      mask |= (c0 | (c1 << 1)) << (2 * pr);
+    }
+    // the scan region of a level is [3, w-4]
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+      if (x + p < 3 || x + p > L.w - 4) mask &= ~(1u << p);
+    if (mask) {
+      const int n = __popc(mask);
+      int pos = atomicAdd(&q_count, n);
+#pragma unroll
+      for (int p = 0; p < 4; p++)
+        if (mask & (1u << p)) queue[pos++] = (unsigned short)(ry * TILE_W + 4 * tx + p);
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: full score of the survivors ------------------------------------------------------
+  const int nq = q_count;
+  const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
+  uint8_t *ob = reinterpret_cast<uint8_t *>(out_tile);
+  for (int q = threadIdx.x; q < nq; q += 256) {
+    const int idx = queue[q];
+    const int ry = idx >> 7, cx = idx & 127;
+    const uint8_t *c = tb + (ry + 3) * (TILE_DW * 4) + cx + 4;
+    constexpr int RP = TILE_DW * 4;
+    int r[16];
+    r[0] = c[3 * RP];       r[1] = c[3 * RP + 1];   r[2] = c[2 * RP + 2];   r[3] = c[RP + 3];
+    r[4] = c[3];            r[5] = c[-RP + 3];      r[6] = c[-2 * RP + 2];  r[7] = c[-3 * RP + 1];
+    r[8] = c[-3 * RP];      r[9] = c[-3 * RP - 1];  r[10] = c[-2 * RP - 2]; r[11] = c[-RP - 3];
+    r[12] = c[-3];          r[13] = c[RP - 3];      r[14] = c[2 * RP - 2];  r[15] = c[3 * RP - 1];
+    ob[idx] = (uint8_t)fast_score16((int)c[0], r, min_thr);
+  }
+  __syncthreads();
+  // ---- phase 3: coalesced write-back ---------------------------------------------------------------
+#pragma unroll
   for (int half = 0; half < 2; half++) {
     const int ry = ty + 8 * half;
     const int y = y0 + ry, x = x0 + 4 * tx;
     if (y >= L.h || x >= L.pitch) continue;
-    unsigned out = 0;
-    if (y >= 3 && y <= L.h - 4) {
-      // 12-byte windows (columns x-4 .. x+7) of the 7 rows y-3 .. y+3
-      unsigned w[7][3];
-#pragma unroll
-      for (int j = 0; j < 7; j++) {
-#pragma unroll
-        for (int q = 0; q < 3; q++) w[j][q] = tile[(ry + j) * TILE_DW + tx + q];
-      }
-#define PX(j, b) ((w[j][(b) >> 2] >> (8 * ((b) & 3))) & 255u)
-#pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const int xx = x + p;
-        if (xx < 3 || xx > L.w - 4) continue;
-        const int cb = 4 + p;  // byte column of the centre inside the window
-        int r[16];
-        // ring (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-        r[0] = PX(6, cb);      r[1] = PX(6, cb + 1);  r[2] = PX(5, cb + 2);  r[3] = PX(4, cb + 3);
-        r[4] = PX(3, cb + 3);  r[5] = PX(2, cb + 3);  r[6] = PX(1, cb + 2);  r[7] = PX(0, cb + 1);
-        r[8] = PX(0, cb);      r[9] = PX(0, cb - 1);  r[10] = PX(1, cb - 2); r[11] = PX(2, cb - 3);
-        r[12] = PX(3, cb - 3); r[13] = PX(4, cb - 3); r[14] = PX(5, cb - 2); r[15] = PX(6, cb - 1);
-        int s = fast_score16((int)PX(3, cb), r, min_thr);
-        out |= (unsigned)s << (8 * p);
-      }
-#undef PX
-    }
-    *reinterpret_cast<unsigned *>(score + base + (size_t)y * L.pitch + x) = out;
+    *reinterpret_cast<unsigned *>(score + base + (size_t)y * L.pitch + x) = out_tile[ry * (TILE_W / 4) + tx];
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // One wave per FAST cell.  The cell's detection rectangle (the pixels cv::FAST scans inside the
 // reference's ROI: x in [19 + j*wCell, min(18 + (j+1)*wCell, w-20)], likewise y) is staged
-// in LDS with a zero halo: NMS does not see across the seam.  Threshold fallback is decided per cell
-// AFTER NMS (orb_feature_extractor.cpp:263-266).  Candidates leave in raster order.
-constexpr int CELL_MAX = 64;  // wCell, hCell <= 59 by construction (ceil(w/floor(w/30)))
-constexpr int CELL_PITCH = CELL_MAX + 4;
+// in LDS with aligned dword loads; bytes outside the rectangle are zeroed, which is exactly "NMS does not see
+// across the seam".  One NMS sweep evaluates both thresholds and keeps the per-chunk ballots; the threshold
+// fallback is decided per cell AFTER NMS (orb_feature_extractor.cpp:263-266); candidates leave in raster order.
+constexpr int CELL_MAX = 64;             // wCell, hCell <= 64 (checked at context creation)
+constexpr int CELL_PITCH = CELL_MAX + 8; // 72 bytes = 18 dwords: 4-byte halo + up to 3 bytes of alignment slack
+constexpr int CELL_DW = CELL_PITCH / 4;
 
-__device__ __forceinline__ bool nms_keep(const uint8_t *s, int idx, int thr) {
-  int v = s[idx];
-  if (v < thr) return false;
-  bool keep = true;
+__device__ __forceinline__ void nms_both(const uint8_t *s, int idx, int t_hi, int t_lo, bool &keep_hi, bool &keep_lo) {
+  const int v = s[idx];
+  keep_hi = keep_lo = false;
+  if (v < t_lo) return;  // the score map holds 0 below fast_min
+  int nmax_lo = 0, nmax_hi = 0;
 #pragma unroll
   for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
     for (int dx = -1; dx <= 1; dx++) {
       if (dx == 0 && dy == 0) continue;
-      int n = s[idx + dy * CELL_PITCH + dx];
-      n = n >= thr ? n : 0;
-      keep = keep && (v > n);
+      const int n = s[idx + dy * CELL_PITCH + dx];
+      nmax_lo = max(nmax_lo, n >= t_lo ? n : 0);
+      nmax_hi = max(nmax_hi, n >= t_hi ? n : 0);
     }
-  return keep;
+  keep_lo = v > nmax_lo;
+  keep_hi = v >= t_hi && v > nmax_hi;
 }
 
 __global__ __launch_bounds__(64) void k_cell_detect(const uint8_t *__restrict__ score, DeviceGeom g,
                                                     CellEntry *__restrict__ cells, unsigned *__restrict__ cands,
                                                     int *__restrict__ cand_count) {
-  __shared__ uint8_t s[(CELL_MAX + 2) * CELL_PITCH];
+  __shared__ unsigned s32[(CELL_MAX + 2) * CELL_DW];
+  __shared__ unsigned long long m_hi[CELL_MAX], m_lo[CELL_MAX];
   const int f = blockIdx.y;
   int c = blockIdx.x, l = 0;
 #pragma unroll 1
@@ -154,31 +246,61 @@ __global__ __launch_bounds__(64) void k_cell_detect(const uint8_t *__restrict__ 
     return;
   }
   const uint8_t *src = score + (size_t)f * g.frame_bytes + L.off;
-  for (int k = lane; k < (rh + 2) * CELL_PITCH; k += 64) {
-    int yy = k / CELL_PITCH, xx = k - yy * CELL_PITCH;
-    uint8_t v = 0;
-    if (yy >= 1 && yy <= rh && xx >= 1 && xx <= rw) v = src[(size_t)(y0 + yy - 1) * L.pitch + x0 + xx - 1];
-    s[k] = v;
+  const int xa = x0 & ~3;                      // LDS column of level x is x - xa + 4
+  const int ndw = (x1 + 1 - xa + 4) / 4 + 1;   // dwords per staged row
+  const int ntot = (rh + 2) * ndw;
+  for (int k0 = 0; k0 < ntot; k0 += 256) {
+    unsigned v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + 64 * u + lane;
+      v[u] = 0;
+      if (k < ntot) {
+        const int r = k / ndw, cdw = k - r * ndw;
+        const int y = y0 - 1 + r, xs = xa - 4 + 4 * cdw;
+        if (y >= y0 && y <= y1 && xs + 3 >= x0 && xs <= x1) {
+          unsigned w = *reinterpret_cast<const unsigned *>(src + (size_t)y * L.pitch + xs);
+          unsigned m = 0;
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            if (xs + b >= x0 && xs + b <= x1) m |= 0xffu << (8 * b);
+          v[u] = w & m;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + 64 * u + lane;
+      if (k < ntot) {
+        const int r = k / ndw, cdw = k - r * ndw;
+        s32[r * CELL_DW + cdw] = v[u];
+      }
+    }
   }
   __syncthreads();
 
+  const uint8_t *s = reinterpret_cast<const uint8_t *>(s32);
+  const int col0 = x0 - xa + 4;
   const int npx = rw * rh;
-  int thr = g.fast_init;
-  int total = 0;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; pass++) {
-    for (int k0 = 0; k0 < npx; k0 += 64) {
-      int k = k0 + lane;
-      bool keep = false;
-      if (k < npx) {
-        int yy = k / rw, xx = k - yy * rw;
-        keep = nms_keep(s, (yy + 1) * CELL_PITCH + xx + 1, thr);
-      }
-      total += __popcll(__ballot(keep));
+  const int nchunks = (npx + 63) / 64;
+  int tot_hi = 0, tot_lo = 0;
+  for (int ch = 0; ch < nchunks; ch++) {
+    const int k = ch * 64 + lane;
+    bool kh = false, kl = false;
+    if (k < npx) {
+      const int yy = k / rw, xx = k - yy * rw;
+      nms_both(s, (yy + 1) * CELL_PITCH + col0 + xx, g.fast_init, g.fast_min, kh, kl);
     }
-    if (total > 0 || thr == g.fast_min) break;
-    thr = g.fast_min;
+    const unsigned long long bh = __ballot(kh), bl = __ballot(kl);
+    tot_hi += __popcll(bh);
+    tot_lo += __popcll(bl);
+    if (lane == 0) {
+      m_hi[ch] = bh;
+      m_lo[ch] = bl;
+    }
   }
+  const bool use_hi = tot_hi > 0;
+  const int total = use_hi ? tot_hi : tot_lo;
   int basei = 0;
   if (lane == 0) {
     if (total > 0) basei = atomicAdd(&cand_count[f * g.levels + l], total);
@@ -186,21 +308,17 @@ __global__ __launch_bounds__(64) void k_cell_detect(const uint8_t *__restrict__ 
   }
   if (total == 0) return;
   basei = __shfl(basei, 0);
+  __syncthreads();
   unsigned *out = cands + (size_t)f * g.cands_per_frame + L.cand_off + basei;
   int run = 0;
-  for (int k0 = 0; k0 < npx; k0 += 64) {
-    int k = k0 + lane;
-    bool keep = false;
-    int yy = 0, xx = 0;
-    if (k < npx) {
-      yy = k / rw;
-      xx = k - yy * rw;
-      keep = nms_keep(s, (yy + 1) * CELL_PITCH + xx + 1, thr);
-    }
-    unsigned long long m = __ballot(keep);
-    if (keep) {
-      int pos = run + __popcll(m & ((1ull << lane) - 1ull));
-      out[pos] = pack_cand(x0 + xx - ORB_MIN_BORDER, y0 + yy - ORB_MIN_BORDER, s[(yy + 1) * CELL_PITCH + xx + 1]);
+  for (int ch = 0; ch < nchunks; ch++) {
+    const unsigned long long m = use_hi ? m_hi[ch] : m_lo[ch];
+    if (m == 0) continue;
+    if ((m >> lane) & 1ull) {
+      const int k = ch * 64 + lane;
+      const int yy = k / rw, xx = k - yy * rw;
+      const int pos = run + __popcll(m & ((1ull << lane) - 1ull));
+      out[pos] = pack_cand(x0 + xx - ORB_MIN_BORDER, y0 + yy - ORB_MIN_BORDER, s[(yy + 1) * CELL_PITCH + col0 + xx]);
     }
     run += __popcll(m);
   }
