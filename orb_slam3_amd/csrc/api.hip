@@ -62,7 +62,7 @@ int build_geometry(orbgpu_ctx *ctx) {
   int budget[ORBGPU_MAX_LEVELS];
   level_budget(p.scale_factor, p.levels, p.max_features, budget);
   unsigned off = 0;
-  int cell_off = 0, cand_off = 0, kp_off = 0, tile_off = 0, xt = 0, yt = 0;
+  int cell_off = 0, cand_off = 0, kp_off = 0, tile_off = 0, ftile_off = 0, xt = 0, yt = 0;
   for (int l = 0; l < p.levels; l++) {
     LevelGeom &L = g.lv[l];
     const float s = (float)ctx->inv_scale[l];  // :506-508
@@ -93,6 +93,8 @@ int build_geometry(orbgpu_ctx *ctx) {
     kp_off += L.kp_cap;
     L.tile_off = tile_off;
     tile_off += ((L.w + 127) / 128) * ((L.h + 15) / 16);
+    L.ftile_off = ftile_off;
+    ftile_off += ((L.w + 127) / 128) * ((L.h + 31) / 32);
     L.xtab_off = xt;
     L.ytab_off = yt;
     xt += L.w;
@@ -105,6 +107,7 @@ int build_geometry(orbgpu_ctx *ctx) {
   g.cands_per_frame = cand_off;
   g.kps_per_frame = kp_off;
   g.tiles_per_frame = tile_off;
+  g.ftiles_per_frame = ftile_off;
   return 0;
 }
 

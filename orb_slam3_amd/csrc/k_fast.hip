@@ -46,6 +46,27 @@ __device__ __forceinline__ int fast_score16(int v, const int (&r)[16], int min_t
   return s >= min_thr ? s : 0;
 }
 
+// the same score for a pixel that already passed the opposite-pair test (no early-out)
+__device__ __forceinline__ int fast_score16_full(int v, const int (&r)[16], int min_thr) {
+  int d[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = v - r[k];
+  int mn3[16], mx3[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    mn3[k] = imin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    mx3[k] = imax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+  }
+  int m_dark = -255, m_brightneg = 255;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    m_dark = max(m_dark, imin3(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
+    m_brightneg = min(m_brightneg, imax3(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
+  }
+  int s = max(m_dark, -m_brightneg) - 1;
+  return s >= min_thr ? s : 0;
+}
+
 // One launch covers all levels of all frames: blockIdx.x = tile over (level, ty, tx), blockIdx.y = frame.
 // Tile 128 x 16 output pixels, staged with a 3-row / 4-column apron as dwords.
 //   phase 1: every lane runs the cheap opposite-pair test on 2 rows x 2 pixel PAIRS in packed u16 math
@@ -68,104 +89,121 @@ __device__ __forceinline__ u16x2 pair_bytes(const unsigned (&w)[3]) {
   return as_u16x2(__builtin_amdgcn_perm(hi, w[lo], sel));
 }
 
+constexpr int FT_H = 32;                 // FAST tile: 128 x 32 pixels, 256 threads, 4 px x 4 rows per thread
+constexpr int FT_ROWS = FT_H + 6;
+
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score,
                                                     DeviceGeom g) {
-  __shared__ unsigned tile[(TILE_H + 6) * TILE_DW];
-  __shared__ unsigned out_tile[TILE_H * TILE_W / 4];
-  __shared__ unsigned short queue[TILE_H * TILE_W];
+  __shared__ unsigned tile[FT_ROWS * TILE_DW];
+  __shared__ unsigned out_tile[FT_H * TILE_W / 4];
+  __shared__ unsigned short queue[FT_H * TILE_W];
   __shared__ int q_count;
   int t = blockIdx.x, l = 0;
 #pragma unroll 1
-  while (l + 1 < g.levels && t >= g.lv[l + 1].tile_off) l++;
+  while (l + 1 < g.levels && t >= g.lv[l + 1].ftile_off) l++;
   const LevelGeom L = g.lv[l];
-  t -= L.tile_off;
+  t -= L.ftile_off;
   const int tiles_x = (L.w + TILE_W - 1) / TILE_W;
-  const int x0 = (t % tiles_x) * TILE_W, y0 = (t / tiles_x) * TILE_H;
+  const int x0 = (t % tiles_x) * TILE_W, y0 = (t / tiles_x) * FT_H;
   const size_t base = (size_t)blockIdx.y * g.frame_bytes + L.off;
   const uint8_t *src = pyr + base;
 
   if (threadIdx.x == 0) q_count = 0;
-  out_tile[threadIdx.x] = 0;
-  out_tile[threadIdx.x + 256] = 0;
-  {
-    // 22 x 34 dwords; pixels outside the image are never part of a scored ring
-    unsigned v[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < FT_H * TILE_W / 4 / 256; k++) out_tile[threadIdx.x + 256 * k] = 0;
+  {
+    // 38 x 34 dwords; pixels outside the image are never part of a scored ring
+    constexpr int NLD = (FT_ROWS * TILE_DW + 255) / 256;
+    unsigned v[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
       const int i = threadIdx.x + 256 * k;
       const int r = i / TILE_DW, c = i - r * TILE_DW;
       const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * c;
       v[k] = 0;
-      if (i < (TILE_H + 6) * TILE_DW && gy >= 0 && gy < L.h && gx >= 0 && gx < L.pitch)
+      if (i < FT_ROWS * TILE_DW && gy >= 0 && gy < L.h && gx >= 0 && gx < L.pitch)
         v[k] = *reinterpret_cast<const unsigned *>(src + (size_t)gy * L.pitch + gx);
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < NLD; k++) {
       const int i = threadIdx.x + 256 * k;
-      if (i < (TILE_H + 6) * TILE_DW) tile[i] = v[k];
+      if (i < FT_ROWS * TILE_DW) tile[i] = v[k];
     }
   }
   __syncthreads();
 
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int lane = threadIdx.x & 63;
   const int min_thr = g.fast_min;
   const u16x2 thr2 = {(unsigned short)min_thr, (unsigned short)min_thr};
   // ---- phase 1: packed quick test -------------------------------------------------------------
-#pragma unroll
-  for (int half = 0; half < 2; half++) {
-    const int ry = ty + 8 * half;
+#pragma unroll 1
+  for (int part = 0; part < FT_H / 8; part++) {
+    const int ry = ty + 8 * part;
     const int y = y0 + ry, x = x0 + 4 * tx;
-    if (y < 3 || y > L.h - 4) continue;
     unsigned mask = 0;  // bit p: pixel x+p may be a corner
-#pragma unroll
-    for (int pr = 0; pr < 2; pr++) {
-      // 12-byte windows (columns x-4 .. x+7) of the 7 rows y-3 .. y+3; pair = pixels x+2pr, x+2pr+1
+    if (y >= 3 && y <= L.h - 4) {
+      // 12-byte windows (columns x-4 .. x+7) of the 7 rows y-3 .. y+3
       unsigned w[7][3];
 #pragma unroll
       for (int j = 0; j < 7; j++)
 #pragma unroll
         for (int q = 0; q < 3; q++) w[j][q] = tile[(ry + j) * TILE_DW + tx + q];
-      constexpr int dummy = 0;
-      (void)dummy;
-      u16x2 r[16];
-      // ring (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-      if (pr == 0) {
-        r[0] = pair_bytes<4>(w[6]);  r[1] = pair_bytes<5>(w[6]);  r[2] = pair_bytes<6>(w[5]);  r[3] = pair_bytes<7>(w[4]);
-        r[4] = pair_bytes<7>(w[3]);  r[5] = pair_bytes<7>(w[2]);  r[6] = pair_bytes<6>(w[1]);  r[7] = pair_bytes<5>(w[0]);
-        r[8] = pair_bytes<4>(w[0]);  r[9] = pair_bytes<3>(w[0]);  r[10] = pair_bytes<2>(w[1]); r[11] = pair_bytes<1>(w[2]);
-        r[12] = pair_bytes<1>(w[3]); r[13] = pair_bytes<1>(w[4]); r[14] = pair_bytes<2>(w[5]); r[15] = pair_bytes<3>(w[6]);
-      } else {
-        r[0] = pair_bytes<6>(w[6]);  r[1] = pair_bytes<7>(w[6]);  r[2] = pair_bytes<8>(w[5]);  r[3] = pair_bytes<9>(w[4]);
-        r[4] = pair_bytes<9>(w[3]);  r[5] = pair_bytes<9>(w[2]);  r[6] = pair_bytes<8>(w[1]);  r[7] = pair_bytes<7>(w[0]);
-        r[8] = pair_bytes<6>(w[0]);  r[9] = pair_bytes<5>(w[0]);  r[10] = pair_bytes<4>(w[1]); r[11] = pair_bytes<3>(w[2]);
-        r[12] = pair_bytes<3>(w[3]); r[13] = pair_bytes<3>(w[4]); r[14] = pair_bytes<4>(w[5]); r[15] = pair_bytes<5>(w[6]);
-      }
-      const u16x2 v = pr == 0 ? pair_bytes<4>(w[3]) : pair_bytes<6>(w[3]);
-      // dark 9-arc needs min(ring_k, ring_k+8) < v - t for all 8 opposite pairs, bright max(...) > v + t
-      u16x2 mx_of_min = __builtin_elementwise_min(r[0], r[8]);
-      u16x2 mn_of_max = __builtin_elementwise_max(r[0], r[8]);
 #pragma unroll
-      for (int k = 1; k < 8; k++) {
-        mx_of_min = __builtin_elementwise_max(mx_of_min, __builtin_elementwise_min(r[k], r[k + 8]));
-        mn_of_max = __builtin_elementwise_min(mn_of_max, __builtin_elementwise_max(r[k], r[k + 8]));
-      }
-      // all values are 0..255 (+t): plain u16 arithmetic cannot wrap
-      const u16x2 dark_lim = mx_of_min + thr2;   // candidate iff dark_lim < v
-      const u16x2 bright_lim = v + thr2;         // candidate iff bright_lim < mn_of_max
-      const unsigned c0 = (dark_lim.x < v.x) | (bright_lim.x < mn_of_max.x);
-      const unsigned c1 = (dark_lim.y < v.y) | (bright_lim.y < mn_of_max.y);
-      mask |= (c0 | (c1 << 1)) << (2 * pr);
-    }
-    // the scan region of a level is [3, w-4]
+      for (int pr = 0; pr < 2; pr++) {
+        u16x2 r[16];
+        // pair = pixels x+2pr, x+2pr+1
+        // ring (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+        if (pr == 0) {
+          r[0] = pair_bytes<4>(w[6]);  r[1] = pair_bytes<5>(w[6]);  r[2] = pair_bytes<6>(w[5]);  r[3] = pair_bytes<7>(w[4]);
+          r[4] = pair_bytes<7>(w[3]);  r[5] = pair_bytes<7>(w[2]);  r[6] = pair_bytes<6>(w[1]);  r[7] = pair_bytes<5>(w[0]);
+          r[8] = pair_bytes<4>(w[0]);  r[9] = pair_bytes<3>(w[0]);  r[10] = pair_bytes<2>(w[1]); r[11] = pair_bytes<1>(w[2]);
+          r[12] = pair_bytes<1>(w[3]); r[13] = pair_bytes<1>(w[4]); r[14] = pair_bytes<2>(w[5]); r[15] = pair_bytes<3>(w[6]);
+        } else {
+          r[0] = pair_bytes<6>(w[6]);  r[1] = pair_bytes<7>(w[6]);  r[2] = pair_bytes<8>(w[5]);  r[3] = pair_bytes<9>(w[4]);
+          r[4] = pair_bytes<9>(w[3]);  r[5] = pair_bytes<9>(w[2]);  r[6] = pair_bytes<8>(w[1]);  r[7] = pair_bytes<7>(w[0]);
+          r[8] = pair_bytes<6>(w[0]);  r[9] = pair_bytes<5>(w[0]);  r[10] = pair_bytes<4>(w[1]); r[11] = pair_bytes<3>(w[2]);
+          r[12] = pair_bytes<3>(w[3]); r[13] = pair_bytes<3>(w[4]); r[14] = pair_bytes<4>(w[5]); r[15] = pair_bytes<5>(w[6]);
+        }
+        const u16x2 v = pr == 0 ? pair_bytes<4>(w[3]) : pair_bytes<6>(w[3]);
+        // dark 9-arc needs min(ring_k, ring_k+8) < v - t for all 8 opposite pairs, bright max(...) > v + t
+        u16x2 mx_of_min = __builtin_elementwise_min(r[0], r[8]);
+        u16x2 mn_of_max = __builtin_elementwise_max(r[0], r[8]);
 #pragma unroll
-    for (int p = 0; p < 4; p++)
-      if (x + p < 3 || x + p > L.w - 4) mask &= ~(1u << p);
-    if (mask) {
-      const int n = __popc(mask);
-      int pos = atomicAdd(&q_count, n);
+        for (int k = 1; k < 8; k++) {
+          mx_of_min = __builtin_elementwise_max(mx_of_min, __builtin_elementwise_min(r[k], r[k + 8]));
+          mn_of_max = __builtin_elementwise_min(mn_of_max, __builtin_elementwise_max(r[k], r[k + 8]));
+        }
+        // all values are 0..255 (+t): plain u16 arithmetic cannot wrap
+        const u16x2 dark_lim = mx_of_min + thr2;   // candidate iff dark_lim < v
+        const u16x2 bright_lim = v + thr2;         // candidate iff bright_lim < mn_of_max
+        const unsigned c0 = (dark_lim.x < v.x) | (bright_lim.x < mn_of_max.x);
+        const unsigned c1 = (dark_lim.y < v.y) | (bright_lim.y < mn_of_max.y);
+        mask |= (c0 | (c1 << 1)) << (2 * pr);
+      }
+      // the scan region of a level is [3, w-4]
 #pragma unroll
       for (int p = 0; p < 4; p++)
-        if (mask & (1u << p)) queue[pos++] = (unsigned short)(ry * TILE_W + 4 * tx + p);
+        if (x + p < 3 || x + p > L.w - 4) mask &= ~(1u << p);
+    }
+    // wave-aggregated push: one LDS atomic per wave and iteration
+    unsigned long long b[4];
+    int tot = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      b[p] = __ballot((mask >> p) & 1u);
+      tot += __popcll(b[p]);
+    }
+    if (tot) {
+      int basep = 0;
+      if (lane == 0) basep = atomicAdd(&q_count, tot);
+      basep = __shfl(basep, 0);
+      const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        if ((mask >> p) & 1u) queue[basep + __popcll(b[p] & below)] = (unsigned short)(ry * TILE_W + 4 * tx + p);
+        basep += __popcll(b[p]);
+      }
     }
   }
   __syncthreads();
@@ -183,13 +221,13 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     r[4] = c[3];            r[5] = c[-RP + 3];      r[6] = c[-2 * RP + 2];  r[7] = c[-3 * RP + 1];
     r[8] = c[-3 * RP];      r[9] = c[-3 * RP - 1];  r[10] = c[-2 * RP - 2]; r[11] = c[-RP - 3];
     r[12] = c[-3];          r[13] = c[RP - 3];      r[14] = c[2 * RP - 2];  r[15] = c[3 * RP - 1];
-    ob[idx] = (uint8_t)fast_score16((int)c[0], r, min_thr);
+    ob[idx] = (uint8_t)fast_score16_full((int)c[0], r, min_thr);
   }
   __syncthreads();
   // ---- phase 3: coalesced write-back ---------------------------------------------------------------
 #pragma unroll
-  for (int half = 0; half < 2; half++) {
-    const int ry = ty + 8 * half;
+  for (int part = 0; part < FT_H / 8; part++) {
+    const int ry = ty + 8 * part;
     const int y = y0 + ry, x = x0 + 4 * tx;
     if (y >= L.h || x >= L.pitch) continue;
     *reinterpret_cast<unsigned *>(score + base + (size_t)y * L.pitch + x) = out_tile[ry * (TILE_W / 4) + tx];
@@ -364,7 +402,7 @@ __global__ __launch_bounds__(256) void k_pack_cands(const unsigned *__restrict__
 }  // namespace
 
 void launch_fast_score(const orbgpu_ctx *c, int n_frames) {
-  dim3 grid(c->geom.tiles_per_frame, n_frames);
+  dim3 grid(c->geom.ftiles_per_frame, n_frames);
   hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_score, c->geom);
 }
 

@@ -24,7 +24,8 @@ struct LevelGeom {
   int cell_off;                    // first cell of this level in a frame's cell table
   int cand_off, cand_cap;          // candidate sub-pool (u32 entries) inside a frame's candidate slab
   int kp_off, kp_cap;              // keypoint slots of this level inside a frame's keypoint slab
-  int tile_off;                    // first 128x16 tile of this level in the all-level tile index
+  int tile_off;                    // first 128x16 tile of this level in the all-level tile index (blur)
+  int ftile_off;                   // first 128x32 tile of this level in the FAST tile index
   int xtab_off, ytab_off;          // resize coefficient tables (entries)
   int kp_size;                     // int(31 * scale_factors_[l])
   float scale_f;                   // (float)scale_factors_[l]
@@ -38,6 +39,7 @@ struct DeviceGeom {
   int cands_per_frame;
   int kps_per_frame;      // sum of kp_cap
   int tiles_per_frame;
+  int ftiles_per_frame;
   LevelGeom lv[ORBGPU_MAX_LEVELS];
 };
 
