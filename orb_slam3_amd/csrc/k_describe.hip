@@ -10,9 +10,11 @@
 
 namespace {
 
-__constant__ signed char c_pattern[256 * 4] = {
+// 256 tests x (x0, y0, x1, y1) signed bytes; read as one dword per test
+__constant__ __attribute__((aligned(16))) signed char c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
+#define c_pattern4 (reinterpret_cast<const unsigned *>(c_pattern))
 
 // umax_, orb_feature_extractor.cpp:678-679
 __constant__ int c_umax[ORB_HALF_PATCH + 1] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
@@ -43,26 +45,34 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 constexpr int PR = 19;              // patch radius staged for the descriptor (taps reach <= 18.4 px)
-constexpr int PW = 2 * PR + 1;      // 39
-constexpr int PPITCH = 40;
+constexpr int PW = 2 * PR + 1;      // 39 rows
+constexpr int PDW = 11;             // aligned dwords per staged row: 39 bytes + up to 3 bytes of misalignment
+constexpr int PPITCH = PDW * 4;     // 44
+constexpr int KPB = 8;              // keypoints (waves) per workgroup
+constexpr int ODW = 9;              // aligned dwords covering the 31-byte orientation rows
 
-// blockDim = 256 = 4 waves = 4 keypoint slots; grid.x = ceil(kps_per_frame / 4), grid.y = frame
-__global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
+// packed pattern: one dword per test = (x0, y0, x1, y1) as signed bytes
+__device__ __forceinline__ int sbyte(unsigned v, int k) { return (int)(signed char)((v >> (8 * k)) & 255u); }
+
+// blockDim = 512 = 8 waves = 8 keypoint slots; grid.x = ceil(kps_per_frame / 8), grid.y = frame
+__global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                          DeviceGeom g, const short2 *__restrict__ kp_xy,
                                                          const int *__restrict__ kp_count,
                                                          orbgpu_keypoint *__restrict__ out_kp,
                                                          uint8_t *__restrict__ out_desc, int capacity,
                                                          int *__restrict__ out_n) {
-  __shared__ uint8_t patch[4][PW * PPITCH];
+  __shared__ unsigned patch[KPB][PW * PDW];
+  __shared__ float s_angle[KPB];
+  __shared__ float s_cs[KPB][2];
   const int f = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * 4 + wave;
+  const int slot = blockIdx.x * KPB + wave;
   const int *cnt = kp_count + f * g.levels;
   // total and per-level prefix (<= 16 levels; every lane computes the same scalars)
   int total = 0;
   for (int l = 0; l < g.levels; l++) total += cnt[l];
   if (blockIdx.x == 0 && threadIdx.x == 0) out_n[f] = total;
-  // validity is wave-uniform; invalid waves fall through to the barrier and write nothing
+  // validity is wave-uniform; invalid waves only take part in the barriers
   bool valid = slot < g.kps_per_frame && total <= capacity;
   int l = 0;
 #pragma unroll 1
@@ -73,32 +83,55 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
   int before = 0;
   for (int q = 0; q < l; q++) before += cnt[q];
   const int pos = total - 1 - (before + i);  // reversed packing, SURVEY App. B.4
-  if (!valid) {
-    __syncthreads();
-    return;
-  }
 
-  const short2 xy = kp_xy[(size_t)f * g.kps_per_frame + slot];
-  const int cx = xy.x, cy = xy.y;
-  const size_t base = (size_t)f * g.frame_bytes + L.off;
-
-  // ---- orientation on the unblurred level: lanes 0..30 = columns u = -15..15 of rows -15..0,
-  //      lanes 32..62 = the same columns of rows 1..15; every row read is 31 contiguous bytes.
-  int m10 = 0, m01 = 0;
-  {
-    const int u = (lane & 31) - ORB_HALF_PATCH;
-    const int hi = lane >> 5;
-    const uint8_t *center = pyr + base + (size_t)cy * L.pitch + cx;
-    if ((lane & 31) < ORB_PATCH) {
-      const int au = u < 0 ? -u : u;
-      for (int k = 0; k < 16; k++) {
-        int v = hi ? (k + 1) : (k - ORB_HALF_PATCH);  // rows 1..16 (16 is masked) / -15..0
-        if (v > ORB_HALF_PATCH) break;
-        int av = v < 0 ? -v : v;
-        if (au <= c_umax[av]) {
-          int val = center[v * L.pitch + u];
-          m10 += u * val;
-          m01 += v * val;
+  int cx = 0, cy = 0;
+  float angle = 0.f;
+  int sh = 0;
+  if (valid) {
+    const short2 xy = kp_xy[(size_t)f * g.kps_per_frame + slot];
+    cx = xy.x;
+    cy = xy.y;
+    const size_t base = (size_t)f * g.frame_bytes + L.off;
+    // ---- issue the blurred-patch loads first (39 rows x 11 aligned dwords), they land during the orientation
+    const int xb = (cx - PR) & ~3;
+    sh = (cx - PR) - xb;
+    unsigned pv[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      const int t = lane + 64 * k;
+      const int r = t / PDW, c = t - r * PDW;
+      pv[k] = 0;
+      if (t < PW * PDW) pv[k] = *reinterpret_cast<const unsigned *>(blur + base + (size_t)(cy - PR + r) * L.pitch + xb + 4 * c);
+    }
+    // ---- orientation on the unblurred level (IC_Angle): 31 rows x 9 aligned dwords, one dword per lane-task;
+    //      m10 = sum u*I, m01 = sum v*I over the disc |u| <= umax[|v|]
+    const int xo = (cx - ORB_HALF_PATCH) & ~3;
+    unsigned ov[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int t = lane + 64 * k;
+      const int r = t / ODW, c = t - r * ODW;
+      ov[k] = 0;
+      if (t < ORB_PATCH * ODW)
+        ov[k] = *reinterpret_cast<const unsigned *>(pyr + base + (size_t)(cy - ORB_HALF_PATCH + r) * L.pitch + xo + 4 * c);
+    }
+    int m10 = 0, m01 = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int t = lane + 64 * k;
+      const int r = t / ODW, c = t - r * ODW;
+      if (t < ORB_PATCH * ODW) {
+        const int v = r - ORB_HALF_PATCH;
+        const int um = c_umax[v < 0 ? -v : v];
+        const int u0 = xo + 4 * c - cx;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const int u = u0 + b;
+          const int val = (int)((ov[k] >> (8 * b)) & 255u);
+          if (u >= -um && u <= um) {
+            m10 += u * val;
+            m01 += v * val;
+          }
         }
       }
     }
@@ -107,36 +140,42 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
       m10 += __shfl_xor(m10, off);
       m01 += __shfl_xor(m01, off);
     }
-  }
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-  // ---- stage the blurred patch (39 x 39) in LDS, coalesced row reads
-  uint8_t *P = patch[wave];
-  {
-    const uint8_t *src = blur + base + (size_t)(cy - PR) * L.pitch + (cx - PR);
-    for (int k = lane; k < PW * PPITCH; k += 64) {
-      int r = k / PPITCH, c = k - r * PPITCH;
-      P[k] = c < PW ? src[(size_t)r * L.pitch + c] : 0;
+    angle = fast_atan2_deg((float)m01, (float)m10);
+    if (lane == 0) s_angle[wave] = angle;
+    unsigned *P = patch[wave];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      const int t = lane + 64 * k;
+      if (t < PW * PDW) P[t] = pv[k];
     }
   }
-  // ---- rotated BRIEF: float(angle_deg) * (double)(pi/180) -> float; cos/sin evaluated in double and
-  //      rounded to float; taps = cvRound(x*b + y*a), cvRound(x*a - y*b), no FMA.
-  const double factorPI = 3.14159265358979323846 / 180.;
-  const float ang = (float)((double)angle * factorPI);
-  const float a = (float)cos((double)ang), b = (float)sin((double)ang);
   __syncthreads();
+  // ---- cos/sin for the whole workgroup by 8 lanes of wave 0: float(angle_deg) * (double)(pi/180) -> float,
+  //      cos/sin evaluated in double and rounded to float
+  if (threadIdx.x < KPB) {
+    const double factorPI = 3.14159265358979323846 / 180.;
+    const float ang = (float)((double)s_angle[threadIdx.x] * factorPI);
+    s_cs[threadIdx.x][0] = (float)cos((double)ang);
+    s_cs[threadIdx.x][1] = (float)sin((double)ang);
+  }
+  __syncthreads();
+  if (!valid) return;
+  const float a = s_cs[wave][0], b = s_cs[wave][1];
+  // ---- rotated BRIEF: taps = cvRound(x*b + y*a), cvRound(x*a - y*b), float32 without FMA
+  const uint8_t *P8 = reinterpret_cast<const uint8_t *>(patch[wave]);
+  const int pc = PR + sh;  // byte column of the keypoint inside a staged row
   unsigned long long bits[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int t = 64 * q + lane;
-    const float x0 = (float)c_pattern[4 * t + 0], y0 = (float)c_pattern[4 * t + 1];
-    const float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
+    const unsigned pt = c_pattern4[64 * q + lane];
+    const float x0 = (float)sbyte(pt, 0), y0 = (float)sbyte(pt, 1);
+    const float x1 = (float)sbyte(pt, 2), y1 = (float)sbyte(pt, 3);
     const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
     const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
     const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
     const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = P[(PR + r0) * PPITCH + PR + c0];
-    const int t1 = P[(PR + r1) * PPITCH + PR + c1];
+    const int t0 = P8[(PR + r0) * PPITCH + pc + c0];
+    const int t1 = P8[(PR + r1) * PPITCH + pc + c1];
     bits[q] = __ballot(t0 < t1);  // bit k of byte i = test 8i + k: ballot order is the descriptor's byte order
   }
   if (lane == 0) {
@@ -161,7 +200,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const uint8_t *__restri
 
 void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                             int *d_n_out) {
-  dim3 grid((c->geom.kps_per_frame + 3) / 4, n_frames);
-  hipLaunchKernelGGL(k_orient_describe, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_blur, c->geom, c->d_kp_xy,
+  dim3 grid((c->geom.kps_per_frame + KPB - 1) / KPB, n_frames);
+  hipLaunchKernelGGL(k_orient_describe, grid, dim3(64 * KPB), 0, c->stream, c->d_pyr, c->d_blur, c->geom, c->d_kp_xy,
                      c->d_kp_count, d_kp, d_desc, capacity, d_n_out);
 }
