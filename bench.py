@@ -137,7 +137,7 @@ def main():
     pipeline = {"algorithmic_bytes_per_frame": A, "extract_ms_per_batch": round(st[6], 3),
                 "achieved_GBps": round(A * B / ext_s / 1e9, 2) if ext_s > 0 else 0.0,
                 "frac_of_8TBps": round(A * B / ext_s / 1e9 / hbm_peak, 5) if ext_s > 0 else 0.0,
-                "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast_score", "cells", "quadtree_host", "blur", "orient_describe"), st[:6])},
+                "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast_score", "cells", "quadtree", "blur", "orient_describe"), st[:6])},
                 "link_match_ms_per_batch": round(match_ms_acc[0] / max(args.steps, 1), 3)}
 
     matching = {}

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -184,23 +185,13 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
   return ms;
 }
 
-// The whole extraction pipeline on device-resident level-0 images already imported into ctx->d_pyr.
-int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
-                 int *d_n_out) {
+// Host cross-check path of the quadtree stage (ORBGPU_HOST_QUADTREE=1): candidates are packed and downloaded,
+// quadtree.cpp runs on a few host threads while the GPU blurs, keypoints are uploaded again.
+int host_quadtree_stage(orbgpu_ctx *ctx, int n_frames, const int *budget) {
   const DeviceGeom &g = ctx->geom;
   const int L = g.levels;
-  int budget[ORBGPU_MAX_LEVELS];
-  level_budget(ctx->params.scale_factor, L, feature_count, budget);
-
-  HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-  for (int l = 1; l < L; l++) launch_pyramid_level(ctx, n_frames, l);
-  HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-  launch_fast_score(ctx, n_frames);
-  HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-  launch_cell_detect(ctx, n_frames);
-  launch_pack_cands(ctx, n_frames);
-  HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
   const int n_fl = n_frames * L;
+  launch_pack_cands(ctx, n_frames);
   HIP_TRY(hipMemcpyAsync(ctx->h_cand_count, ctx->d_cand_count, sizeof(int) * n_fl, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->h_cand_prefix, ctx->d_cand_prefix, sizeof(int) * (n_fl + 1), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->h_cells, ctx->d_cells, sizeof(CellEntry) * (size_t)n_frames * g.cells_per_frame,
@@ -218,16 +209,9 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   if (total_cands)
     HIP_TRY(hipMemcpyAsync(ctx->h_cands, ctx->d_cands_packed, sizeof(unsigned) * total_cands, hipMemcpyDeviceToHost,
                            ctx->stream));
-  // blur runs on the GPU while the host distributes keypoints
-  HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
-  launch_blur(ctx, n_frames);
-  HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
-  // wait for the candidates only (the copy was enqueued before the blur)
-  HIP_TRY(hipEventSynchronize(ctx->ev[4]));
-
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   const auto t0 = std::chrono::steady_clock::now();
   {
-    // host quadtree, one task per (frame, level), a few worker threads
     const int n_tasks = n_fl;
     std::atomic<int> next{0};
     std::atomic<int> bad{0};
@@ -260,27 +244,68 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     }
     if (bad.load()) return fail(ctx, ORBGPU_E_CAPACITY, "quadtree produced more keypoints than the level capacity");
   }
-  const auto t1 = std::chrono::steady_clock::now();
+  ctx->quadtree_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   HIP_TRY(hipMemcpyAsync(ctx->d_kp_xy, ctx->h_kp_xy, sizeof(short2) * (size_t)n_frames * g.kps_per_frame,
                          hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->d_kp_count, ctx->h_kp_count, sizeof(int) * n_fl, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
+  return 0;
+}
+
+// The whole extraction pipeline on device-resident level-0 images already imported into ctx->d_pyr.
+// Everything is enqueued on the context's stream; nothing here waits for the GPU unless the host cross-check
+// quadtree is selected.  Stage times and the device error flag are collected by finish_pipeline().
+int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
+                 int *d_n_out) {
+  const DeviceGeom &g = ctx->geom;
+  const int L = g.levels;
+  int budget[ORBGPU_MAX_LEVELS];
+  level_budget(ctx->params.scale_factor, L, feature_count, budget);
+  ctx->quadtree_host_ms = 0.f;
+  HIP_TRY(hipMemsetAsync(ctx->d_error_flag, 0, sizeof(int), ctx->stream));
+  HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  for (int l = 1; l < L; l++) launch_pyramid_level(ctx, n_frames, l);
+  HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+  launch_fast_score(ctx, n_frames);
+  HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+  launch_cell_detect(ctx, n_frames);
+  HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+  if (ctx->host_quadtree) {
+    int rc = host_quadtree_stage(ctx, n_frames, budget);
+    if (rc) return rc;
+  } else {
+    if (launch_quadtree(ctx, n_frames, budget) != 0)
+      return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
+  }
+  HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+  launch_blur(ctx, n_frames);
+  HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
   launch_orient_describe(ctx, n_frames, d_kp, d_desc, capacity, d_n_out);
-  HIP_TRY(hipEventRecord(ctx->ev[7], ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  ctx->stage_ms[0] = elapsed(ctx->ev[0], ctx->ev[1]);
-  ctx->stage_ms[1] = elapsed(ctx->ev[1], ctx->ev[2]);
-  ctx->stage_ms[2] = elapsed(ctx->ev[2], ctx->ev[3]);
-  ctx->stage_ms[3] = std::chrono::duration<float, std::milli>(t1 - t0).count();
-  ctx->stage_ms[4] = elapsed(ctx->ev[4], ctx->ev[5]);
-  ctx->stage_ms[5] = elapsed(ctx->ev[6], ctx->ev[7]);
-  ctx->stage_ms[6] = elapsed(ctx->ev[0], ctx->ev[7]);
+  HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_error_flag, ctx->d_error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipGetLastError());
+  ctx->timing_pending = true;
   ctx->last_frames = n_frames;
   ctx->last_feature_count = feature_count;
-  for (int f = 0; f < n_frames; f++) {
-    int tot = 0;
-    for (int l = 0; l < L; l++) tot += ctx->h_kp_count[f * L + l];
-    if (tot > capacity) return fail(ctx, ORBGPU_E_CAPACITY, "keypoint capacity too small: need " + std::to_string(tot));
+  return 0;
+}
+
+// waits for the stream, turns the device error flag into a status and reads the stage timers
+int finish_pipeline(orbgpu_ctx *ctx) {
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->timing_pending) {
+    ctx->timing_pending = false;
+    ctx->stage_ms[0] = elapsed(ctx->ev[0], ctx->ev[1]);
+    ctx->stage_ms[1] = elapsed(ctx->ev[1], ctx->ev[2]);
+    ctx->stage_ms[2] = elapsed(ctx->ev[2], ctx->ev[3]);
+    ctx->stage_ms[3] = ctx->host_quadtree ? ctx->quadtree_host_ms : elapsed(ctx->ev[3], ctx->ev[4]);
+    ctx->stage_ms[4] = elapsed(ctx->ev[4], ctx->ev[5]);
+    ctx->stage_ms[5] = elapsed(ctx->ev[5], ctx->ev[6]);
+    ctx->stage_ms[6] = elapsed(ctx->ev[0], ctx->ev[6]);
+    if (*ctx->h_error_flag != 0) {
+      const int code = *ctx->h_error_flag;
+      *ctx->h_error_flag = 0;
+      return fail(ctx, ORBGPU_E_CAPACITY, "quadtree kernel capacity violation (code " + std::to_string(code) + ")");
+    }
   }
   return 0;
 }
@@ -331,6 +356,10 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   orbgpu_ctx *ctx = new orbgpu_ctx();
   ctx->params = *params;
   ctx->device = params->device;
+  {
+    const char *e = std::getenv("ORBGPU_HOST_QUADTREE");
+    ctx->host_quadtree = e && e[0] == '1';
+  }
   auto bail = [&](int rc) {
     g_create_error = ctx->err;
     orbgpu_destroy(ctx);
@@ -361,6 +390,11 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(dmalloc(&ctx->d_cells, B * g.cells_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cands, B * g.cands_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cands_packed, B * g.cands_per_frame));
+    HIP_TRY(dmalloc(&ctx->d_cands_tmp, B * g.cands_per_frame));
+    HIP_TRY(dmalloc(&ctx->d_cell_prefix, B * g.cells_per_frame));
+    HIP_TRY(dmalloc(&ctx->d_error_flag, 1));
+    HIP_TRY(hmalloc(&ctx->h_error_flag, 1));
+    *ctx->h_error_flag = 0;
     HIP_TRY(dmalloc(&ctx->d_cand_count, B * g.levels));
     HIP_TRY(dmalloc(&ctx->d_cand_prefix, B * g.levels + 1));
     HIP_TRY(dmalloc(&ctx->d_kp_xy, B * g.kps_per_frame));
@@ -391,10 +425,11 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_cand_count, ctx->d_cand_prefix, ctx->d_kp_xy, ctx->d_kp_count,
-                   ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch};
+                   ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix,
+                   ctx->d_error_flag};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
-  void *hptrs[] = {ctx->h_cand_count, ctx->h_cand_prefix, ctx->h_cells, ctx->h_cands, ctx->h_kp_xy, ctx->h_kp_count, ctx->h_imgs};
+  void *hptrs[] = {ctx->h_cand_count, ctx->h_cand_prefix, ctx->h_cells, ctx->h_cands, ctx->h_kp_xy, ctx->h_kp_count, ctx->h_imgs, ctx->h_error_flag};
   for (void *p : hptrs)
     if (p) (void)hipHostFree(p);
   for (auto &ev : ctx->ev)
@@ -427,8 +462,8 @@ void *orbgpu_stream(orbgpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullpt
 
 int orbgpu_synchronize(orbgpu_ctx *ctx) {
   if (!ctx) return ORBGPU_E_INVALID;
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return ORBGPU_OK;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  return finish_pipeline(ctx);
 }
 
 int orbgpu_extract_batch_device(orbgpu_ctx *ctx, const uint8_t *d_imgs, int64_t frame_stride, int32_t stride,
@@ -477,10 +512,12 @@ int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_
   const int cap_dev = ctx->out_capacity;
   int rc = run_pipeline(ctx, n_frames, feature_count, ctx->d_out_kp, ctx->d_out_desc, cap_dev, ctx->d_out_n);
   if (rc) return rc;
-  const int L = ctx->geom.levels;
+  HIP_TRY(hipMemcpyAsync(ctx->h_kp_count, ctx->d_out_n, sizeof(int) * n_frames, hipMemcpyDeviceToHost, ctx->stream));
+  rc = finish_pipeline(ctx);
+  if (rc) return rc;
   for (int f = 0; f < n_frames; f++) {
-    int tot = 0;
-    for (int l = 0; l < L; l++) tot += ctx->h_kp_count[f * L + l];
+    const int tot = ctx->h_kp_count[f];
+    if (tot > cap_dev) return fail(ctx, ORBGPU_E_CAPACITY, "internal keypoint capacity too small: need " + std::to_string(tot));
     if (tot > capacity) return fail(ctx, ORBGPU_E_CAPACITY, "caller capacity too small: need " + std::to_string(tot));
     n_out[f] = tot;
     if (tot) {
@@ -527,12 +564,18 @@ int orbgpu_debug_dump(orbgpu_ctx *ctx, int32_t frame, uint8_t *pyramid, uint8_t 
     }
   }
   if (n_cand_per_level || cand_x) {
+    // candidates of the frame: cell table + sub-pools straight from the device, walked in reference order
+    std::vector<CellEntry> cells_h((size_t)g.cells_per_frame);
+    std::vector<unsigned> pool((size_t)g.cands_per_frame);
+    HIP_TRY(hipMemcpy(cells_h.data(), ctx->d_cells + (size_t)frame * g.cells_per_frame, sizeof(CellEntry) * cells_h.size(),
+                      hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pool.data(), ctx->d_cands + (size_t)frame * g.cands_per_frame, sizeof(unsigned) * pool.size(),
+                      hipMemcpyDeviceToHost));
     int n = 0;
     for (int l = 0; l < g.levels; l++) {
-      const int t = frame * g.levels + l;
       const LevelGeom &L = g.lv[l];
-      const unsigned *c = ctx->h_cands + ctx->h_cand_prefix[t];
-      const CellEntry *cells = ctx->h_cells + (size_t)frame * g.cells_per_frame + L.cell_off;
+      const unsigned *c = pool.data() + L.cand_off;
+      const CellEntry *cells = cells_h.data() + L.cell_off;
       int nl = 0;
       for (int ci = 0; ci < L.ncols * L.nrows; ci++)
         for (int k = 0; k < cells[ci].count; k++) {
@@ -697,6 +740,8 @@ int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to,
 int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms7) {
   if (!ctx || !ms7) return ORBGPU_E_INVALID;
   std::lock_guard<std::mutex> lock(ctx->mu);
+  int rc = finish_pipeline(ctx);
+  if (rc) return rc;
   for (int i = 0; i < 7; i++) ms7[i] = ctx->stage_ms[i];
   return ORBGPU_OK;
 }

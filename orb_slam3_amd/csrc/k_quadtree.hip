@@ -1,0 +1,505 @@
+// Quadtree keypoint distribution on the GPU: one workgroup per (frame, level).  gfx950 only.
+//
+// Reference stage: ORBFeatureExtractor::DistributeOctTree src/features/orb_feature_extractor.cpp:300-502 and
+// ExtractorNode::DivideNode :602-652.  Same formulation as the host version in quadtree.cpp (which stays as the
+// cross-check path): the std::list is an array in list order; every sweep rebuilds it as
+//     reverse(children in creation order) ++ (surviving old nodes in order),
+// keys of a node are a contiguous segment of a key buffer and a division is a stable 4-way partition of that
+// segment into the OTHER key buffer (segments of live nodes are disjoint, so nothing live is overwritten).
+//   phase 1 (:356-423)  every multi-key node is divided per sweep;
+//   phase 2 (:424-480)  the multi-key children of the last sweep are divided largest first
+//                       (std::sort on (size, node*) -- ties: later-created first) until the list
+//                       holds nFeatures nodes: ranks by counting, cut by a prefix sum over the processing order;
+//   finally (:486-501)  the first maximum-response key of each node is emitted in list order.
+// Parallel decomposition: nodes with many keys are partitioned by a whole wave (ballot prefix compaction),
+// small nodes by single lanes; list positions come from workgroup-wide prefix sums.
+#include "orbgpu_internal.h"
+
+namespace {
+
+constexpr int QT_THREADS = 256;
+constexpr int QT_WAVES = QT_THREADS / 64;
+constexpr int QT_LDS_KEYS = 2048;   // keys per ping-pong buffer kept in LDS; larger levels use global scratch
+constexpr int QT_SMALL = 24;        // nodes up to this many keys are partitioned by one lane
+
+struct QNode {
+  unsigned short x0, x1, y0, y1;  // UL.x, UR.x, UL.y, BR.y
+  unsigned beg;                   // first key of the segment
+  unsigned cnt;                   // bit 31: key buffer (0 = A, 1 = B); bits 0..30: number of keys
+};
+static_assert(sizeof(QNode) == 16, "QNode layout");
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ int key_x(unsigned k) { return (int)(k & 0xfffu); }
+__device__ __forceinline__ int key_y(unsigned k) { return (int)((k >> 12) & 0xfffu); }
+__device__ __forceinline__ int key_resp(unsigned k) { return (int)(k >> 24); }
+
+struct QShared {
+  unsigned *keys[2];
+  QNode *cur, *nxt;
+  uint4 *qc;            // quadrant counts of list entry i
+  u64 *pre;             // packed prefix sums per entry (3 x 21 bit)
+  u64 *pre2;            // survivor positions in phase 2
+  unsigned short *vs, *vs_new, *ord;
+  unsigned char *flag;
+};
+
+// exclusive prefix sum over a[0..n) in place (LDS), all QT_THREADS threads; returns the total
+__device__ u64 block_excl_scan(u64 *a, int n, u64 *wsum) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u64 carry = 0;
+  for (int base = 0; base < n; base += QT_THREADS) {
+    const int i = base + threadIdx.x;
+    const u64 v = i < n ? a[i] : 0;
+    u64 incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const u64 o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u64 woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < QT_WAVES; w++) {
+      const u64 s = wsum[w];
+      if (w < wave) woff += s;
+      tot += s;
+    }
+    if (i < n) a[i] = carry + woff + incl - v;
+    carry += tot;
+    __syncthreads();
+  }
+  return carry;
+}
+
+__device__ __forceinline__ int quadrant(unsigned key, int mx, int my) {
+  return (key_x(key) < mx ? 0 : 1) + (key_y(key) < my ? 0 : 2);  // n1 n2 / n3 n4, :637-645
+}
+
+// stable 4-way partition of src[beg, beg+cnt) into dst[beg, ...) by a whole wave; returns the quadrant counts
+__device__ uint4 partition_wave(const unsigned *src, unsigned *dst, int beg, int cnt, int mx, int my) {
+  const int lane = threadIdx.x & 63;
+  const u64 below = (1ull << lane) - 1ull;
+  int c[4] = {0, 0, 0, 0};
+  for (int k0 = 0; k0 < cnt; k0 += 64) {
+    const int k = k0 + lane;
+    const bool ok = k < cnt;
+    const int q = ok ? quadrant(src[beg + k], mx, my) : -1;
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) c[qq] += __popcll(__ballot(q == qq));
+  }
+  int o[4];
+  o[0] = beg;
+  o[1] = o[0] + c[0];
+  o[2] = o[1] + c[1];
+  o[3] = o[2] + c[2];
+  for (int k0 = 0; k0 < cnt; k0 += 64) {
+    const int k = k0 + lane;
+    const bool ok = k < cnt;
+    const unsigned key = ok ? src[beg + k] : 0u;
+    const int q = ok ? quadrant(key, mx, my) : -1;
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) {
+      const u64 b = __ballot(q == qq);
+      if (q == qq) dst[o[qq] + __popcll(b & below)] = key;
+      o[qq] += __popcll(b);
+    }
+  }
+  return make_uint4((unsigned)c[0], (unsigned)c[1], (unsigned)c[2], (unsigned)c[3]);
+}
+
+// the same by one lane
+__device__ uint4 partition_lane(const unsigned *src, unsigned *dst, int beg, int cnt, int mx, int my) {
+  int c[4] = {0, 0, 0, 0};
+  for (int k = 0; k < cnt; k++) {
+    const int q = quadrant(src[beg + k], mx, my);
+    c[0] += q == 0; c[1] += q == 1; c[2] += q == 2; c[3] += q == 3;
+  }
+  int o[4];
+  o[0] = beg;
+  o[1] = o[0] + c[0];
+  o[2] = o[1] + c[1];
+  o[3] = o[2] + c[2];
+  for (int k = 0; k < cnt; k++) {
+    const unsigned key = src[beg + k];
+    const int q = quadrant(key, mx, my);
+    // o[] indexed dynamically would go to scratch; select instead
+    int p;
+    if (q == 0) p = o[0]++;
+    else if (q == 1) p = o[1]++;
+    else if (q == 2) p = o[2]++;
+    else p = o[3]++;
+    dst[p] = key;
+  }
+  return make_uint4((unsigned)c[0], (unsigned)c[1], (unsigned)c[2], (unsigned)c[3]);
+}
+
+__device__ __forceinline__ void node_mid(const QNode &P, int &mx, int &my) {
+  mx = P.x0 + ((P.x1 - P.x0 + 1) >> 1);  // ceil(float(w)/2), :606
+  my = P.y0 + ((P.y1 - P.y0 + 1) >> 1);  // :607
+}
+
+// divide the keys of the listed nodes (list positions idx[k], or k itself when idx == nullptr)
+__device__ void partition_nodes(const QShared &S, const unsigned short *idx, int count) {
+  const int wave = threadIdx.x >> 6;
+  // large nodes: one wave each
+  for (int k = wave; k < count; k += QT_WAVES) {
+    const int i = idx ? idx[k] : k;
+    const QNode P = S.cur[i];
+    const int cnt = (int)(P.cnt & 0x7fffffffu);
+    if (cnt <= QT_SMALL) continue;
+    const int b = (int)(P.cnt >> 31);
+    int mx, my;
+    node_mid(P, mx, my);
+    const uint4 c = partition_wave(S.keys[b], S.keys[b ^ 1], (int)P.beg, cnt, mx, my);
+    if ((threadIdx.x & 63) == 0) S.qc[i] = c;
+  }
+  // small nodes: one lane each
+  for (int k = threadIdx.x; k < count; k += QT_THREADS) {
+    const int i = idx ? idx[k] : k;
+    const QNode P = S.cur[i];
+    const int cnt = (int)(P.cnt & 0x7fffffffu);
+    if (cnt > QT_SMALL) continue;
+    uint4 c = make_uint4(0, 0, 0, 0);
+    if (cnt > 1) {
+      const int b = (int)(P.cnt >> 31);
+      int mx, my;
+      node_mid(P, mx, my);
+      c = partition_lane(S.keys[b], S.keys[b ^ 1], (int)P.beg, cnt, mx, my);
+    }
+    S.qc[i] = c;
+  }
+}
+
+__device__ __forceinline__ u64 pack3(unsigned a, unsigned b, unsigned c) { return (u64)a | ((u64)b << 21) | ((u64)c << 42); }
+__device__ __forceinline__ unsigned f0(u64 v) { return (unsigned)(v & 0x1fffffu); }
+__device__ __forceinline__ unsigned f1(u64 v) { return (unsigned)((v >> 21) & 0x1fffffu); }
+__device__ __forceinline__ unsigned f2(u64 v) { return (unsigned)((v >> 42) & 0x1fffffu); }
+
+// write the children of parent P (quadrant counts c) into the new list: creation index `cidx` onwards, positions
+// counted from the back of the `ct` children (push_front order); multi-key children are appended to vs_new at `midx`
+__device__ void emit_children(const QShared &S, const QNode &P, const uint4 c, int cidx, int ct, int midx) {
+  int mx, my;
+  node_mid(P, mx, my);
+  const unsigned nb = ((P.cnt >> 31) ^ 1u) << 31;
+  const unsigned cq[4] = {c.x, c.y, c.z, c.w};
+  const unsigned short bx0[4] = {P.x0, (unsigned short)mx, P.x0, (unsigned short)mx};
+  const unsigned short bx1[4] = {(unsigned short)mx, P.x1, (unsigned short)mx, P.x1};
+  const unsigned short by0[4] = {P.y0, P.y0, (unsigned short)my, (unsigned short)my};
+  const unsigned short by1[4] = {(unsigned short)my, (unsigned short)my, P.y1, P.y1};
+  unsigned beg = P.beg;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    if (cq[q] != 0) {
+      const int pos = ct - 1 - cidx;
+      QNode n;
+      n.x0 = bx0[q]; n.x1 = bx1[q]; n.y0 = by0[q]; n.y1 = by1[q];
+      n.beg = beg;
+      n.cnt = cq[q] | nb;
+      S.nxt[pos] = n;
+      if (cq[q] > 1) S.vs_new[midx++] = (unsigned short)pos;
+      cidx++;
+    }
+    beg += cq[q];
+  }
+}
+
+__device__ __forceinline__ unsigned n_children(const uint4 c) { return (c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0); }
+__device__ __forceinline__ unsigned n_multi(const uint4 c) { return (c.x > 1) + (c.y > 1) + (c.z > 1) + (c.w > 1); }
+
+struct QtArgs {
+  const CellEntry *cells;      // [frame][cells_per_frame]
+  const unsigned *cands;       // [frame][cands_per_frame] candidate sub-pools
+  unsigned *buf_a, *buf_b;     // [frame][cands_per_frame] ordered key buffers (global fallback / gather target)
+  int *cell_prefix;            // [frame][cells_per_frame]
+  short2 *kp_xy;               // [frame][kps_per_frame]
+  int *kp_count;               // [frame][levels]
+  int *error_flag;
+  int node_cap;                // LDS entries per list array
+  int budget[ORBGPU_MAX_LEVELS];
+  int nini[ORBGPU_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ u64 wsum[QT_WAVES];
+  __shared__ int s_misc[8];
+  const int l = blockIdx.x, f = blockIdx.y;
+  const LevelGeom L = g.lv[l];
+  const int cap = a.node_cap;
+  const int nF = a.budget[l];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // carve the dynamic LDS
+  QShared S;
+  unsigned char *p = smem;
+  unsigned *lds_keys = reinterpret_cast<unsigned *>(p); p += sizeof(unsigned) * 2 * QT_LDS_KEYS;
+  QNode *nodes0 = reinterpret_cast<QNode *>(p); p += sizeof(QNode) * cap;
+  QNode *nodes1 = reinterpret_cast<QNode *>(p); p += sizeof(QNode) * cap;
+  S.qc = reinterpret_cast<uint4 *>(p); p += sizeof(uint4) * cap;
+  S.pre = reinterpret_cast<u64 *>(p); p += sizeof(u64) * cap;
+  S.pre2 = reinterpret_cast<u64 *>(p); p += sizeof(u64) * cap;
+  S.vs = reinterpret_cast<unsigned short *>(p); p += sizeof(unsigned short) * cap;
+  S.vs_new = reinterpret_cast<unsigned short *>(p); p += sizeof(unsigned short) * cap;
+  S.ord = reinterpret_cast<unsigned short *>(p); p += sizeof(unsigned short) * cap;
+  S.flag = p;
+  S.cur = nodes0;
+  S.nxt = nodes1;
+
+  // ---- gather the candidates in reference order: cells row-major, raster order inside a cell (:244-276) ----
+  const int n_cells = L.ncols * L.nrows;
+  const CellEntry *cells = a.cells + (size_t)f * g.cells_per_frame + L.cell_off;
+  int *cpre = a.cell_prefix + (size_t)f * g.cells_per_frame + L.cell_off;
+  int n = 0;
+  {
+    int carry = 0;
+    for (int base = 0; base < n_cells; base += QT_THREADS) {
+      const int i = base + tid;
+      const int v = i < n_cells ? cells[i].count : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) wsum[wave] = (u64)incl;
+      __syncthreads();
+      int woff = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < QT_WAVES; w++) {
+        const int s = (int)wsum[w];
+        if (w < wave) woff += s;
+        tot += s;
+      }
+      if (i < n_cells) cpre[i] = carry + woff + incl - v;
+      carry += tot;
+      __syncthreads();
+    }
+    n = carry;
+  }
+  const bool in_lds = n <= QT_LDS_KEYS;
+  const size_t goff = (size_t)f * g.cands_per_frame + L.cand_off;
+  S.keys[0] = in_lds ? lds_keys : a.buf_a + goff;
+  S.keys[1] = in_lds ? lds_keys + QT_LDS_KEYS : a.buf_b + goff;
+  {
+    const unsigned *pool = a.cands + goff;
+    unsigned *dst = S.keys[0];
+    for (int c = tid; c < n_cells; c += QT_THREADS) {
+      const CellEntry ce = cells[c];
+      const int o = cpre[c];
+      for (int k = 0; k < ce.count; k++) dst[o + k] = pool[ce.off + k];
+    }
+  }
+  __syncthreads();
+
+  // ---- root nodes (:310-347): nIni vertical strips, keys bucketed by int(x / hX), stable ----
+  const int W = L.w - 2 * ORB_MIN_BORDER, H = L.h - 2 * ORB_MIN_BORDER;
+  const int nIni = a.nini[l];
+  const float hX = __fdiv_rn((float)W, (float)nIni);
+  int Sz = 0;  // list size
+  if (nIni == 1) {
+    if (tid == 0 && n > 0) {
+      QNode r;
+      r.x0 = 0; r.x1 = (unsigned short)(int)__fmul_rn(hX, 1.0f); r.y0 = 0; r.y1 = (unsigned short)H;
+      r.beg = 0; r.cnt = (unsigned)n;
+      S.cur[0] = r;
+    }
+    Sz = n > 0 ? 1 : 0;
+  } else {
+    // wave 0 splits the keys bucket by bucket into buffer B, then the roots live in B
+    if (wave == 0) {
+      const u64 below = (1ull << lane) - 1ull;
+      int o = 0, nroots = 0;
+      for (int b = 0; b < nIni; b++) {
+        const int beg = o;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+          const int k = k0 + lane;
+          const bool ok = k < n;
+          const unsigned key = ok ? S.keys[0][k] : 0u;
+          int bk = ok ? (int)__fdiv_rn((float)key_x(key), hX) : -1;
+          if (ok) bk = min(max(bk, 0), nIni - 1);
+          const u64 m = __ballot(bk == b);
+          if (bk == b) S.keys[1][o + __popcll(m & below)] = key;
+          o += __popcll(m);
+        }
+        if (o > beg) {  // empty roots are erased (:343-344)
+          if (lane == 0) {
+            QNode r;
+            r.x0 = (unsigned short)(int)__fmul_rn(hX, (float)b);
+            r.x1 = (unsigned short)(int)__fmul_rn(hX, (float)(b + 1));
+            r.y0 = 0; r.y1 = (unsigned short)H;
+            r.beg = (unsigned)beg; r.cnt = (unsigned)(o - beg) | 0x80000000u;
+            S.cur[nroots] = r;
+          }
+          nroots++;
+        }
+      }
+      if (lane == 0) s_misc[0] = nroots;
+    }
+    __syncthreads();
+    Sz = s_misc[0];
+  }
+  __syncthreads();
+
+  // ---- phase 1 ----------------------------------------------------------------------------------------
+  bool finish = false;
+  bool phase2 = false;
+  int n_vs = 0;
+  while (!finish && !phase2) {
+    const int prevSize = Sz;
+    partition_nodes(S, nullptr, Sz);
+    __syncthreads();
+    for (int i = tid; i < Sz; i += QT_THREADS) {
+      const unsigned cnt = S.cur[i].cnt & 0x7fffffffu;
+      const uint4 c = S.qc[i];
+      S.pre[i] = cnt > 1 ? pack3(n_children(c), 0, n_multi(c)) : pack3(0, 1, 0);
+    }
+    __syncthreads();
+    const u64 tot = block_excl_scan(S.pre, Sz, wsum);
+    const int ct = (int)f0(tot), kt = (int)f1(tot), mt = (int)f2(tot);
+    if (ct + kt > cap) {  // cannot happen: the list never exceeds max(nF + 3, 4 nIni)
+      if (tid == 0) atomicExch(a.error_flag, 1);
+      Sz = 0;
+      break;
+    }
+    for (int i = tid; i < Sz; i += QT_THREADS) {
+      const QNode P = S.cur[i];
+      const u64 pr = S.pre[i];
+      if ((P.cnt & 0x7fffffffu) > 1) emit_children(S, P, S.qc[i], (int)f0(pr), ct, (int)f2(pr));
+      else S.nxt[ct + (int)f1(pr)] = P;
+    }
+    __syncthreads();
+    { QNode *t = S.cur; S.cur = S.nxt; S.nxt = t; }
+    { unsigned short *t = S.vs; S.vs = S.vs_new; S.vs_new = t; }
+    Sz = ct + kt;
+    n_vs = mt;
+    if (Sz >= nF || Sz == prevSize) finish = true;           // :422
+    else if (Sz + n_vs * 3 > nF) phase2 = true;                // :424
+  }
+
+  // ---- phase 2 ----------------------------------------------------------------------------------------
+  while (!finish && phase2) {
+    const int prevSize = Sz;
+    const int m = n_vs;
+    if (m == 0) break;  // nothing left to divide: size == prevSize (:477)
+    partition_nodes(S, S.vs, m);
+    // processing order: descending (size, creation order); rank by counting
+    for (int k = tid; k < m; k += QT_THREADS) {
+      const unsigned ck = S.cur[S.vs[k]].cnt & 0x7fffffffu;
+      int rank = 0;
+      for (int k2 = 0; k2 < m; k2++) {
+        const unsigned c2 = S.cur[S.vs[k2]].cnt & 0x7fffffffu;
+        rank += (c2 > ck) || (c2 == ck && k2 > k);
+      }
+      S.ord[rank] = (unsigned short)k;
+    }
+    for (int i = tid; i < Sz; i += QT_THREADS) S.flag[i] = 0;
+    __syncthreads();
+    // inclusive growth of the list along the processing order -> cut (:474)
+    for (int r = tid; r < m; r += QT_THREADS) {
+      const uint4 c = S.qc[S.vs[S.ord[r]]];
+      S.pre[r] = pack3(n_children(c), 0, n_multi(c));
+    }
+    __syncthreads();
+    block_excl_scan(S.pre, m, wsum);
+    // first r with prevSize + (children through r) - (r + 1) >= nF
+    if (tid == 0) s_misc[1] = m;
+    __syncthreads();
+    for (int r = tid; r < m; r += QT_THREADS) {
+      const uint4 c = S.qc[S.vs[S.ord[r]]];
+      const int grown = prevSize + (int)f0(S.pre[r]) + (int)n_children(c) - (r + 1);
+      if (grown >= nF) atomicMin(&s_misc[1], r + 1);
+    }
+    __syncthreads();
+    const int nproc = s_misc[1];  // nodes actually divided this sweep
+    // totals over the processed prefix
+    int ct, mt;
+    {
+      const int rl = nproc - 1;
+      const uint4 c = S.qc[S.vs[S.ord[rl]]];
+      ct = (int)f0(S.pre[rl]) + (int)n_children(c);
+      mt = (int)f2(S.pre[rl]) + (int)n_multi(c);
+    }
+    for (int r = tid; r < nproc; r += QT_THREADS) S.flag[S.vs[S.ord[r]]] = 1;
+    __syncthreads();
+    // survivors of the old list keep their order behind the new children
+    for (int i = tid; i < Sz; i += QT_THREADS) S.pre2[i] = S.flag[i] ? 0ull : 1ull;
+    __syncthreads();
+    const int kt = (int)block_excl_scan(S.pre2, Sz, wsum);
+    if (ct + kt > cap) {
+      if (tid == 0) atomicExch(a.error_flag, 1);
+      Sz = 0;
+      break;
+    }
+    for (int r = tid; r < nproc; r += QT_THREADS) {
+      const int i = S.vs[S.ord[r]];
+      emit_children(S, S.cur[i], S.qc[i], (int)f0(S.pre[r]), ct, (int)f2(S.pre[r]));
+    }
+    for (int i = tid; i < Sz; i += QT_THREADS)
+      if (!S.flag[i]) S.nxt[ct + (int)S.pre2[i]] = S.cur[i];
+    __syncthreads();
+    { QNode *t = S.cur; S.cur = S.nxt; S.nxt = t; }
+    { unsigned short *t = S.vs; S.vs = S.vs_new; S.vs_new = t; }
+    Sz = ct + kt;
+    n_vs = mt;
+    if (Sz >= nF || Sz == prevSize) finish = true;  // :477
+  }
+
+  // ---- best point of each node: first maximum, strict > (:486-501) ----
+  short2 *out = a.kp_xy + (size_t)f * g.kps_per_frame + L.kp_off;
+  if (Sz > L.kp_cap) {
+    if (tid == 0) atomicExch(a.error_flag, 3);
+    Sz = 0;
+  }
+  for (int i = tid; i < Sz; i += QT_THREADS) {
+    const QNode P = S.cur[i];
+    const unsigned *keys = S.keys[P.cnt >> 31];
+    const int cnt = (int)(P.cnt & 0x7fffffffu);
+    unsigned best = keys[P.beg];
+    for (int k = 1; k < cnt; k++) {
+      const unsigned key = keys[P.beg + k];
+      if (key_resp(key) > key_resp(best)) best = key;
+    }
+    out[i] = make_short2((short)(key_x(best) + ORB_MIN_BORDER), (short)(key_y(best) + ORB_MIN_BORDER));
+  }
+  if (tid == 0) a.kp_count[f * g.levels + l] = Sz;
+}
+
+}  // namespace
+
+size_t quadtree_lds_bytes(int node_cap) {
+  return sizeof(unsigned) * 2 * QT_LDS_KEYS + (size_t)node_cap * (2 * sizeof(QNode) + sizeof(uint4) + 2 * sizeof(u64) + 3 * sizeof(unsigned short) + 1) + 64;
+}
+
+int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
+  const DeviceGeom &g = c->geom;
+  QtArgs a{};
+  a.cells = c->d_cells;
+  a.cands = c->d_cands;
+  a.buf_a = c->d_cands_packed;
+  a.buf_b = c->d_cands_tmp;
+  a.cell_prefix = c->d_cell_prefix;
+  a.kp_xy = c->d_kp_xy;
+  a.kp_count = c->d_kp_count;
+  a.error_flag = c->d_error_flag;
+  int cap = 0;
+  for (int l = 0; l < g.levels; l++) {
+    a.budget[l] = budget[l];
+    a.nini[l] = c->nini[l];
+    cap = std::max(cap, g.lv[l].kp_cap);
+  }
+  cap = (cap + 7) & ~7;
+  a.node_cap = cap;
+  const size_t lds = quadtree_lds_bytes(cap);
+  if (lds > 160 * 1024) return -1;
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return -1;
+    configured = lds;
+  }
+  hipLaunchKernelGGL(k_quadtree, dim3(g.levels, n_frames), dim3(QT_THREADS), lds, c->stream, g, a);
+  return 0;
+}

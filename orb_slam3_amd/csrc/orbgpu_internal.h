@@ -76,7 +76,14 @@ struct orbgpu_ctx {
   unsigned *d_cands = nullptr;    // [frame][cands_per_frame]
   int *d_cand_count = nullptr;    // [frame][levels]
   int *d_cand_prefix = nullptr;   // [frame*levels + 1] exclusive scan of d_cand_count
-  unsigned *d_cands_packed = nullptr;  // dense copy for the host quadtree
+  unsigned *d_cands_packed = nullptr;  // dense copy for the host quadtree / key buffer A of the device quadtree
+  unsigned *d_cands_tmp = nullptr;     // key buffer B of the device quadtree (levels too large for LDS)
+  int *d_cell_prefix = nullptr;        // [frame][cells_per_frame]
+  int *d_error_flag = nullptr;         // set by kernels on capacity violations
+  int *h_error_flag = nullptr;
+  bool host_quadtree = false;          // ORBGPU_HOST_QUADTREE=1: cross-check path (quadtree.cpp)
+  bool timing_pending = false;
+  float quadtree_host_ms = 0.f;
   short2 *d_kp_xy = nullptr;      // [frame][kps_per_frame] level coordinates after the quadtree
   int *d_kp_count = nullptr;      // [frame][levels]
   // internal outputs used by the host-pointer entry points
@@ -116,6 +123,10 @@ void launch_blur(const orbgpu_ctx *c, int n_frames);
 void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                             int *d_n_out);
 void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t frame_stride, int stride, int n_frames);
+
+// device quadtree (k_quadtree.hip); budget = per-level feature budget.  Returns 0 or -1 (LDS too large)
+int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget);
+size_t quadtree_lds_bytes(int node_cap);
 
 // host quadtree (DistributeOctTree), flat-array formulation; returns number of keypoints written
 int quadtree_distribute(const unsigned *cands, const CellEntry *cells, int n_cells, int w, int h, int n_features,

@@ -53,3 +53,47 @@ def test_extract_stage_parity(oracle, w, h, nfeat, seed):
     _kp_equal(ft.keypoints, okp)
     assert np.array_equal(ft.descriptors, odesc)
     fe.close()
+
+
+@pytest.mark.parametrize("w,h,nfeat,levels,seed,scene", [
+    (1920, 1080, 5000, 8, 7, "rich"),    # two quadtree roots (nIni = 2), keys beyond the LDS buffers
+    (640, 480, 30, 8, 8, "rich"),        # tiny budgets: the list overshoots / stops in the first sweeps
+    (640, 480, 6000, 8, 9, "rich"),      # budget above the number of candidates: every node ends as a singleton
+    (480, 640, 800, 6, 10, "rich"),      # portrait
+    (800, 300, 1200, 5, 11, "rich"),     # wide: nIni = 3
+    (640, 480, 1000, 8, 12, "low"),      # low contrast: per-cell threshold fallback everywhere
+    (640, 480, 1000, 8, 13, "noise"),    # white noise: very many candidates per cell
+])
+def test_extract_quadtree_stress(oracle, w, h, nfeat, levels, seed, scene):
+    """keypoints / descriptors of the device quadtree path against the oracle on inputs that stress DistributeOctTree"""
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    img = synth.frame(seed, h, w)
+    if scene == "low":
+        img = (img.astype(np.int32) // 8 + 100).astype(np.uint8)
+    elif scene == "noise":
+        img = np.random.default_rng(seed).integers(0, 256, (h, w)).astype(np.uint8)
+    p = oracle.params(w, h, levels=levels)
+    okp, odesc = oracle.extract_literal(p, img, nfeat)
+    fe = ORBFeatureExtractor(w, h, 1.2, levels, 20, 7, max_features=nfeat)
+    ft = Features(w, h)
+    assert fe.Extract(img, ft, nfeat) == 0
+    _kp_equal(ft.keypoints, okp)
+    assert np.array_equal(ft.descriptors, odesc)
+    fe.close()
+
+
+def test_host_quadtree_cross_check(oracle, monkeypatch):
+    """ORBGPU_HOST_QUADTREE=1 routes the quadtree stage through quadtree.cpp on the host; both paths must agree"""
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    img = synth.frame(31, 480, 640)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("ORBGPU_HOST_QUADTREE", flag)
+        fe = ORBFeatureExtractor(640, 480, 1.2, 8, 20, 7, max_features=1000)
+        ft = Features(640, 480)
+        assert fe.Extract(img, ft, 1000) == 0
+        res.append(ft)
+        fe.close()
+    assert np.array_equal(res[0].keypoints, res[1].keypoints) and np.array_equal(res[0].descriptors, res[1].descriptors)
+    okp, odesc = oracle.extract_literal(oracle.params(640, 480), img, 1000)
+    _kp_equal(res[1].keypoints, okp)
