@@ -81,7 +81,7 @@ int build_geometry(orbgpu_ctx *ctx) {
     L.nrows = (int)(height / 30.f);
     L.wcell = (int)std::ceil(width / (float)L.ncols);
     L.hcell = (int)std::ceil(height / (float)L.nrows);
-    if (L.wcell > 64 || L.hcell > 64) return fail(ctx, ORBGPU_E_INVALID, "FAST cell larger than 64 px");
+    if (L.wcell > 60 || L.hcell > 64) return fail(ctx, ORBGPU_E_INVALID, "FAST cell larger than 60 x 64 px");
     L.cell_off = cell_off;
     cell_off += L.ncols * L.nrows;
     L.cand_off = cand_off;
@@ -191,24 +191,18 @@ int host_quadtree_stage(orbgpu_ctx *ctx, int n_frames, const int *budget) {
   const DeviceGeom &g = ctx->geom;
   const int L = g.levels;
   const int n_fl = n_frames * L;
-  launch_pack_cands(ctx, n_frames);
-  HIP_TRY(hipMemcpyAsync(ctx->h_cand_count, ctx->d_cand_count, sizeof(int) * n_fl, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->h_cand_prefix, ctx->d_cand_prefix, sizeof(int) * (n_fl + 1), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->h_cells, ctx->d_cells, sizeof(CellEntry) * (size_t)n_frames * g.cells_per_frame,
-                         hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  const size_t total_cands = (size_t)ctx->h_cand_prefix[n_fl];
+  // slow by design: the whole cell table and every candidate slot of the batch come down
+  const size_t total_cands = (size_t)n_frames * g.cands_per_frame;
   if (total_cands > ctx->h_cands_cap) {
     if (ctx->h_cands) HIP_TRY(hipHostFree(ctx->h_cands));
     ctx->h_cands = nullptr;
     ctx->h_cands_cap = 0;
-    size_t want = total_cands + total_cands / 2 + 4096;
-    HIP_TRY(hmalloc(&ctx->h_cands, want));
-    ctx->h_cands_cap = want;
+    HIP_TRY(hmalloc(&ctx->h_cands, total_cands));
+    ctx->h_cands_cap = total_cands;
   }
-  if (total_cands)
-    HIP_TRY(hipMemcpyAsync(ctx->h_cands, ctx->d_cands_packed, sizeof(unsigned) * total_cands, hipMemcpyDeviceToHost,
-                           ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_cells, ctx->d_cells, sizeof(CellEntry) * (size_t)n_frames * g.cells_per_frame,
+                         hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_cands, ctx->d_cands, sizeof(unsigned) * total_cands, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const auto t0 = std::chrono::steady_clock::now();
   {
@@ -221,7 +215,7 @@ int host_quadtree_stage(orbgpu_ctx *ctx, int n_frames, const int *budget) {
         if (t >= n_tasks) break;
         const int f = t / L, l = t % L;
         const LevelGeom &G = g.lv[l];
-        const int n = quadtree_distribute(ctx->h_cands + ctx->h_cand_prefix[t],
+        const int n = quadtree_distribute(ctx->h_cands + (size_t)f * g.cands_per_frame + G.cand_off,
                                           ctx->h_cells + (size_t)f * g.cells_per_frame + G.cell_off, G.ncols * G.nrows,
                                           G.w, G.h, budget[l], ctx->h_kp_xy + (size_t)f * g.kps_per_frame + G.kp_off,
                                           G.kp_cap);

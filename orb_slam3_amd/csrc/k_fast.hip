@@ -5,6 +5,8 @@
 // (cv::FAST :259-266).  Closed form used:
 //   d_k = v - ring_k,  M_dark = max over the 16 arcs of min over 9 contiguous d,
 //   M_bright = max over arcs of min(-d),  score = max(M_dark, M_bright) - 1,  corner at t  <=>  score >= t.
+#include <cstdlib>
+
 #include "orbgpu_internal.h"
 
 namespace {
@@ -235,40 +237,33 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// One wave per FAST cell.  The cell's detection rectangle (the pixels cv::FAST scans inside the
-// reference's ROI: x in [19 + j*wCell, min(18 + (j+1)*wCell, w-20)], likewise y) is staged
-// in LDS with aligned dword loads; bytes outside the rectangle are zeroed, which is exactly "NMS does not see
-// across the seam".  One NMS sweep evaluates both thresholds and keeps the per-chunk ballots; the threshold
-// fallback is decided per cell AFTER NMS (orb_feature_extractor.cpp:263-266); candidates leave in raster order.
-constexpr int CELL_MAX = 64;             // wCell, hCell <= 64 (checked at context creation)
-constexpr int CELL_PITCH = CELL_MAX + 8; // 72 bytes = 18 dwords: 4-byte halo + up to 3 bytes of alignment slack
-constexpr int CELL_DW = CELL_PITCH / 4;
+// One wave per FAST cell, four independent waves per workgroup.  The cell's detection rectangle (the pixels
+// cv::FAST scans inside the reference's ROI: x in [19 + j*wCell, min(18 + (j+1)*wCell, w-20)], likewise y; SURVEY
+// App. B.2) is staged in LDS with aligned dword loads (16 dwords x 4 rows per wave step, no integer division);
+// bytes outside the rectangle are zeroed and neighbours outside it read as 0: "NMS does not see across the seam".
+// The score map is ~92 % zeros, so the non-zero pixels are first compacted, in raster order, into an LDS queue and
+// only those are run through the 3x3 NMS -- once, for both thresholds.  The threshold fallback is decided per cell
+// AFTER NMS (orb_feature_extractor.cpp:263-266); survivors leave in raster order.
+constexpr int CELL_MAX = 64;       // rectangle rows; columns must fit 16 aligned dwords (wCell <= 60)
+constexpr int CELL_DW = 16;
+constexpr int CELL_PITCH = CELL_DW * 4;
+constexpr int CQ_CAP = 512;        // queue entries; denser cells take the division-based dense path
+constexpr int CELLS_PER_WG = 4;
 
-__device__ __forceinline__ void nms_both(const uint8_t *s, int idx, int t_hi, int t_lo, bool &keep_hi, bool &keep_lo) {
-  const int v = s[idx];
-  keep_hi = keep_lo = false;
-  if (v < t_lo) return;  // the score map holds 0 below fast_min
-  int nmax_lo = 0, nmax_hi = 0;
-#pragma unroll
-  for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-    for (int dx = -1; dx <= 1; dx++) {
-      if (dx == 0 && dy == 0) continue;
-      const int n = s[idx + dy * CELL_PITCH + dx];
-      nmax_lo = max(nmax_lo, n >= t_lo ? n : 0);
-      nmax_hi = max(nmax_hi, n >= t_hi ? n : 0);
-    }
-  keep_lo = v > nmax_lo;
-  keep_hi = v >= t_hi && v > nmax_hi;
-}
-
-__global__ __launch_bounds__(64) void k_cell_detect(const uint8_t *__restrict__ score, DeviceGeom g,
-                                                    CellEntry *__restrict__ cells, unsigned *__restrict__ cands,
-                                                    int *__restrict__ cand_count) {
-  __shared__ unsigned s32[(CELL_MAX + 2) * CELL_DW];
-  __shared__ unsigned long long m_hi[CELL_MAX], m_lo[CELL_MAX];
+__global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t *__restrict__ score, DeviceGeom g,
+                                                                   CellEntry *__restrict__ cells,
+                                                                   unsigned *__restrict__ cands) {
+  __shared__ unsigned s32_all[CELLS_PER_WG][CELL_MAX * CELL_DW];
+  __shared__ unsigned short queue_all[CELLS_PER_WG][CQ_CAP];
+  __shared__ unsigned long long m_hi_all[CELLS_PER_WG][CELL_MAX], m_lo_all[CELLS_PER_WG][CELL_MAX];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned *s32 = s32_all[wave];
+  const uint8_t *s8 = reinterpret_cast<const uint8_t *>(s32);
+  unsigned short *queue = queue_all[wave];
+  unsigned long long *m_hi = m_hi_all[wave], *m_lo = m_lo_all[wave];
   const int f = blockIdx.y;
-  int c = blockIdx.x, l = 0;
+  int c = blockIdx.x * CELLS_PER_WG + wave, l = 0;
+  if (c >= g.cells_per_frame) return;
 #pragma unroll 1
   while (l + 1 < g.levels && c >= g.lv[l + 1].cell_off) l++;
   const LevelGeom L = g.lv[l];
@@ -277,57 +272,99 @@ __global__ __launch_bounds__(64) void k_cell_detect(const uint8_t *__restrict__ 
   const int x0 = ORB_EDGE + j * L.wcell, x1 = min(ORB_EDGE - 1 + (j + 1) * L.wcell, L.w - ORB_EDGE - 1);
   const int y0 = ORB_EDGE + i * L.hcell, y1 = min(ORB_EDGE - 1 + (i + 1) * L.hcell, L.h - ORB_EDGE - 1);
   const int rw = x1 - x0 + 1, rh = y1 - y0 + 1;
-  const int lane = threadIdx.x;
   CellEntry *ce = cells + (size_t)f * g.cells_per_frame + c;
   if (rw <= 0 || rh <= 0) {
     if (lane == 0) *ce = CellEntry{0, 0};
     return;
   }
   const uint8_t *src = score + (size_t)f * g.frame_bytes + L.off;
-  const int xa = x0 & ~3;                      // LDS column of level x is x - xa + 4
-  const int ndw = (x1 + 1 - xa + 4) / 4 + 1;   // dwords per staged row
-  const int ntot = (rh + 2) * ndw;
-  for (int k0 = 0; k0 < ntot; k0 += 256) {
-    unsigned v[4];
+  const int xa = x0 & ~3;          // staged byte column cx of level x is x - xa
+  const int cxa = x0 - xa;         // first rectangle column, 0..3
+  const int ndwr = (cxa + rw + 3) >> 2;
+  const int dd = lane & 15, rsub = lane >> 4;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // byte mask of this lane's dword column
+  unsigned bmask = 0;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int k = k0 + 64 * u + lane;
-      v[u] = 0;
-      if (k < ntot) {
-        const int r = k / ndw, cdw = k - r * ndw;
-        const int y = y0 - 1 + r, xs = xa - 4 + 4 * cdw;
-        if (y >= y0 && y <= y1 && xs + 3 >= x0 && xs <= x1) {
-          unsigned w = *reinterpret_cast<const unsigned *>(src + (size_t)y * L.pitch + xs);
-          unsigned m = 0;
+  for (int b = 0; b < 4; b++)
+    if (4 * dd + b >= cxa && 4 * dd + b < cxa + rw) bmask |= 0xffu << (8 * b);
+
+  // ---- stage + compact the non-zero pixels (raster order: 4 rows per step, lane = row*16 + dword, then byte) ----
+  int nq = 0;
+  unsigned w[16];  // all row steps in flight at once: rh <= 64 = 16 steps of 4 rows
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int r = 4 * u + rsub;
+    w[u] = 0;
+    if (r < rh && dd < ndwr) w[u] = *reinterpret_cast<const unsigned *>(src + (size_t)(y0 + r) * L.pitch + xa + 4 * dd) & bmask;
+  }
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int r = 4 * u + rsub;
+    if (4 * u < rh) {
+      if (r < rh) s32[r * CELL_DW + dd] = w[u];
+      const unsigned long long any = __ballot(w[u] != 0);
+      if (any != 0) {
+        unsigned long long bb[4];
+        int tot = 0, mine = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          bb[b] = __ballot(((w[u] >> (8 * b)) & 255u) != 0);
+          tot += __popcll(bb[b]);
+          mine += __popcll(bb[b] & below);
+        }
+        if (nq + tot <= CQ_CAP) {
+          int pos = nq + mine;
 #pragma unroll
           for (int b = 0; b < 4; b++)
-            if (xs + b >= x0 && xs + b <= x1) m |= 0xffu << (8 * b);
-          v[u] = w & m;
+            if ((w[u] >> (8 * b)) & 255u) queue[pos++] = (unsigned short)((r << 6) | (4 * dd + b));
         }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int k = k0 + 64 * u + lane;
-      if (k < ntot) {
-        const int r = k / ndw, cdw = k - r * ndw;
-        s32[r * CELL_DW + cdw] = v[u];
+        nq += tot;
       }
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();  // LDS traffic of one wave is processed in order
+  const bool dense = nq > CQ_CAP;   // queue overflow: walk every pixel instead (k -> row, column by division)
+  const int n_ent = dense ? rw * rh : nq;
+  const int nchunks = (n_ent + 63) / 64;
+  const int t_hi = g.fast_init, t_lo = g.fast_min;
 
-  const uint8_t *s = reinterpret_cast<const uint8_t *>(s32);
-  const int col0 = x0 - xa + 4;
-  const int npx = rw * rh;
-  const int nchunks = (npx + 63) / 64;
+  auto entry = [&](int k, int &yy, int &cx) {
+    if (dense) {
+      yy = k / rw;
+      cx = cxa + (k - yy * rw);
+    } else {
+      const int e = queue[k];
+      yy = e >> 6;
+      cx = e & 63;
+    }
+  };
+  auto at = [&](int yy, int cx) -> int {
+    return (yy >= 0 && yy < rh && cx >= cxa && cx < cxa + rw) ? (int)s8[yy * CELL_PITCH + cx] : 0;
+  };
+
   int tot_hi = 0, tot_lo = 0;
   for (int ch = 0; ch < nchunks; ch++) {
     const int k = ch * 64 + lane;
     bool kh = false, kl = false;
-    if (k < npx) {
-      const int yy = k / rw, xx = k - yy * rw;
-      nms_both(s, (yy + 1) * CELL_PITCH + col0 + xx, g.fast_init, g.fast_min, kh, kl);
+    if (k < n_ent) {
+      int yy, cx;
+      entry(k, yy, cx);
+      const int v = s8[yy * CELL_PITCH + cx];
+      if (v >= t_lo) {  // the score map holds 0 below fast_min
+        int nmax_lo = 0, nmax_hi = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+          for (int dx = -1; dx <= 1; dx++) {
+            if (dx == 0 && dy == 0) continue;
+            const int n = at(yy + dy, cx + dx);
+            nmax_lo = max(nmax_lo, n);  // n is 0 or >= t_lo
+            nmax_hi = max(nmax_hi, n >= t_hi ? n : 0);
+          }
+        kl = v > nmax_lo;
+        kh = v >= t_hi && v > nmax_hi;
+      }
     }
     const unsigned long long bh = __ballot(kh), bl = __ballot(kl);
     tot_hi += __popcll(bh);
@@ -339,64 +376,26 @@ __global__ __launch_bounds__(64) void k_cell_detect(const uint8_t *__restrict__ 
   }
   const bool use_hi = tot_hi > 0;
   const int total = use_hi ? tot_hi : tot_lo;
-  int basei = 0;
-  if (lane == 0) {
-    if (total > 0) basei = atomicAdd(&cand_count[f * g.levels + l], total);
-    *ce = CellEntry{basei, total};
-  }
+  // every cell owns a fixed slot of ceil(wCell/2) * ceil(hCell/2) entries in its level's sub-pool: NMS survivors
+  // are never adjacent, so the slot cannot overflow and no atomic is needed
+  const int basei = ci * (((L.wcell + 1) >> 1) * ((L.hcell + 1) >> 1));
+  if (lane == 0) *ce = CellEntry{basei, total};
   if (total == 0) return;
-  basei = __shfl(basei, 0);
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
   unsigned *out = cands + (size_t)f * g.cands_per_frame + L.cand_off + basei;
+  const unsigned long long *mm = use_hi ? m_hi : m_lo;
   int run = 0;
   for (int ch = 0; ch < nchunks; ch++) {
-    const unsigned long long m = use_hi ? m_hi[ch] : m_lo[ch];
+    const unsigned long long m = mm[ch];
     if (m == 0) continue;
     if ((m >> lane) & 1ull) {
-      const int k = ch * 64 + lane;
-      const int yy = k / rw, xx = k - yy * rw;
-      const int pos = run + __popcll(m & ((1ull << lane) - 1ull));
-      out[pos] = pack_cand(x0 + xx - ORB_MIN_BORDER, y0 + yy - ORB_MIN_BORDER, s[(yy + 1) * CELL_PITCH + col0 + xx]);
+      int yy, cx;
+      entry(ch * 64 + lane, yy, cx);
+      out[run + __popcll(m & below)] =
+          pack_cand(x0 + (cx - cxa) - ORB_MIN_BORDER, y0 + yy - ORB_MIN_BORDER, s8[yy * CELL_PITCH + cx]);
     }
     run += __popcll(m);
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// exclusive scan of the (frame, level) candidate counts, then a dense copy of the used part of every
-// sub-pool: the host quadtree downloads one contiguous buffer.
-__global__ __launch_bounds__(1024) void k_scan_counts(const int *__restrict__ count, int n, int *__restrict__ prefix) {
-  __shared__ int part[1024];
-  const int per = (n + 1023) / 1024;
-  const int b = threadIdx.x * per;
-  int sum = 0;
-  for (int i = 0; i < per; i++)
-    if (b + i < n) sum += count[b + i];
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-    __syncthreads();
-    part[threadIdx.x] += v;
-    __syncthreads();
-  }
-  int run = part[threadIdx.x] - sum;
-  for (int i = 0; i < per; i++)
-    if (b + i < n) {
-      prefix[b + i] = run;
-      run += count[b + i];
-    }
-  if (threadIdx.x == 1023) prefix[n] = part[1023];
-}
-
-__global__ __launch_bounds__(256) void k_pack_cands(const unsigned *__restrict__ cands, DeviceGeom g,
-                                                    const int *__restrict__ count, const int *__restrict__ prefix,
-                                                    unsigned *__restrict__ packed) {
-  const int l = blockIdx.x, f = blockIdx.y;
-  const int n = count[f * g.levels + l];
-  const unsigned *src = cands + (size_t)f * g.cands_per_frame + g.lv[l].cand_off;
-  unsigned *dst = packed + prefix[f * g.levels + l];
-  for (int i = blockIdx.z * 256 + threadIdx.x; i < n; i += 256 * gridDim.z) dst[i] = src[i];
 }
 
 }  // namespace
@@ -407,16 +406,6 @@ void launch_fast_score(const orbgpu_ctx *c, int n_frames) {
 }
 
 void launch_cell_detect(const orbgpu_ctx *c, int n_frames) {
-  (void)hipMemsetAsync(c->d_cand_count, 0, sizeof(int) * (size_t)n_frames * c->geom.levels, c->stream);
-  dim3 grid(c->geom.cells_per_frame, n_frames);
-  hipLaunchKernelGGL(k_cell_detect, grid, dim3(64), 0, c->stream, c->d_score, c->geom, c->d_cells, c->d_cands,
-                     c->d_cand_count);
-}
-
-void launch_pack_cands(const orbgpu_ctx *c, int n_frames) {
-  const int n = n_frames * c->geom.levels;
-  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, c->stream, c->d_cand_count, n, c->d_cand_prefix);
-  dim3 grid(c->geom.levels, n_frames, 4);
-  hipLaunchKernelGGL(k_pack_cands, grid, dim3(256), 0, c->stream, c->d_cands, c->geom, c->d_cand_count,
-                     c->d_cand_prefix, c->d_cands_packed);
+  dim3 grid((c->geom.cells_per_frame + CELLS_PER_WG - 1) / CELLS_PER_WG, n_frames);
+  hipLaunchKernelGGL(k_cell_detect, grid, dim3(64 * CELLS_PER_WG), 0, c->stream, c->d_score, c->geom, c->d_cells, c->d_cands);
 }

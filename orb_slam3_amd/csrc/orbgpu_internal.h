@@ -118,7 +118,6 @@ int fail_hip(orbgpu_ctx *ctx, hipError_t e, const char *expr, const char *file, 
 void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level);
 void launch_fast_score(const orbgpu_ctx *c, int n_frames);
 void launch_cell_detect(const orbgpu_ctx *c, int n_frames);
-void launch_pack_cands(const orbgpu_ctx *c, int n_frames);
 void launch_blur(const orbgpu_ctx *c, int n_frames);
 void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                             int *d_n_out);
