@@ -116,85 +116,136 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 // Gaussian blur 7x7, sigma 2, BORDER_REFLECT_101 -- OpenCV's 8.8 fixed-point path:
 //   h = sum k_i * src[x+i-3]            (u16, <= 65280)
 //   dst = (sum k_j * h[y+j-3] + 32768) >> 16
-// One launch covers all levels of all frames.  Tile 128 x 16, apron 3 rows / 4 columns; the u8 tile and
-// the u16 horizontal pass both live in LDS.
+// One launch covers all levels of all frames.  Tile 128 x 32, apron 3 rows / 4 columns, both passes in LDS and in
+// packed integer math (the integer VALU, not HBM, is what bounds this kernel):
+//   horizontal: two pixels per op -- v_perm_b32 builds (tap_p, tap_p+1) u16 pairs, v_pk_add/v_pk_mul_lo/v_pk_mad_u16
+//               evaluate the symmetric taps; two rows per lane are interleaved so that LDS holds (row 2m, row 2m+1)
+//               pairs per pixel;
+//   vertical:   four v_dot2_u32_u16 per pixel on those row pairs (weights chosen by the parity of the output row).
+constexpr int BT_H = 32;
+constexpr int BT_ROWS = BT_H + 6;        // 38 staged rows = 19 row pairs
+constexpr int BT_PAIRS = BT_ROWS / 2;
+
+typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
+__device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+// bytes B and B+1 of the 12-byte window {w0,w1,w2} zero-extended into the two u16 halves
+template <int B>
+__device__ __forceinline__ u16x2 pair_bytes(const unsigned (&w)[3]) {
+  constexpr int lo = B >> 2;
+  constexpr int k0 = B & 3, k1 = k0 + 1;
+  constexpr unsigned sel = (unsigned)k0 | (0x0cu << 8) | ((unsigned)k1 << 16) | (0x0cu << 24);
+  const unsigned hi = w[lo + 1 < 3 ? lo + 1 : 2];
+  return as_u16x2(__builtin_amdgcn_perm(hi, w[lo], sel));
+}
+
+// horizontal 7-tap of the pixel pair whose first tap is byte B of the window
+template <int B>
+__device__ __forceinline__ u16x2 hblur_pair(const unsigned (&w)[3]) {
+  const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
+  const u16x2 s0 = pair_bytes<B>(w) + pair_bytes<B + 6>(w);
+  const u16x2 s1 = pair_bytes<B + 1>(w) + pair_bytes<B + 5>(w);
+  const u16x2 s2 = pair_bytes<B + 2>(w) + pair_bytes<B + 4>(w);
+  return s0 * k18 + s1 * k34 + s2 * k48 + pair_bytes<B + 3>(w) * k56;
+}
+
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g) {
-  __shared__ unsigned tile[(TILE_H + 6) * TILE_DW];
-  __shared__ __attribute__((aligned(8))) unsigned short hbuf[(TILE_H + 6) * TILE_W];
+  __shared__ unsigned tile[BT_ROWS * TILE_DW];
+  __shared__ __attribute__((aligned(16))) unsigned hbuf[BT_PAIRS * TILE_W];  // (h[2m][x], h[2m+1][x]) per dword
   // tile -> (level, tile x, tile y)
   int t = blockIdx.x, l = 0;
 #pragma unroll 1
-  while (l + 1 < g.levels && t >= g.lv[l + 1].tile_off) l++;
+  while (l + 1 < g.levels && t >= g.lv[l + 1].ftile_off) l++;
   const LevelGeom L = g.lv[l];
-  t -= L.tile_off;
+  t -= L.ftile_off;
   const int tiles_x = (L.w + TILE_W - 1) / TILE_W;
-  const int x0 = (t % tiles_x) * TILE_W, y0 = (t / tiles_x) * TILE_H;
+  const int x0 = (t % tiles_x) * TILE_W, y0 = (t / tiles_x) * BT_H;
   const size_t base = (size_t)blockIdx.y * g.frame_bytes + L.off;
   const uint8_t *src = pyr + base;
 
-  for (int i = threadIdx.x; i < (TILE_H + 6) * TILE_DW; i += 256) {
-    int r = i / TILE_DW, c = i - r * TILE_DW;
-    int gy = reflect101(y0 - 3 + r, L.h);
-    int gx = x0 - 4 + 4 * c;
-    unsigned v;
-    if (gx >= 0 && gx + 3 < L.w) {
-      v = *reinterpret_cast<const unsigned *>(src + (size_t)gy * L.pitch + gx);
-    } else {
-      v = 0;
+  {
+    constexpr int NLD = (BT_ROWS * TILE_DW + 255) / 256;
+    unsigned v[NLD];
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-        int xx = gx + b;
-        // columns further than the 3-px apron from the image are never used; clamp keeps them in range
-        xx = reflect101(max(min(xx, L.w + 2), -3), L.w);
-        v |= (unsigned)src[(size_t)gy * L.pitch + xx] << (8 * b);
+    for (int k = 0; k < NLD; k++) {
+      const int i = threadIdx.x + 256 * k;
+      v[k] = 0;
+      if (i < BT_ROWS * TILE_DW) {
+        const int r = i / TILE_DW, c = i - r * TILE_DW;
+        // rows below the image only feed output rows that are not written; keep the index in range
+        const int gy = reflect101(min(y0 - 3 + r, L.h + 2), L.h);
+        const int gx = x0 - 4 + 4 * c;
+        if (gx >= 0 && gx + 3 < L.w) {
+          v[k] = *reinterpret_cast<const unsigned *>(src + (size_t)gy * L.pitch + gx);
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            // columns further than the 3-px apron from the image are never used; the clamp keeps them in range
+            const int xx = reflect101(max(min(gx + b, L.w + 2), -3), L.w);
+            v[k] |= (unsigned)src[(size_t)gy * L.pitch + xx] << (8 * b);
+          }
+        }
       }
     }
-    tile[i] = v;
-  }
-  __syncthreads();
-
-  // horizontal pass over all 22 staged rows
-  for (int i = threadIdx.x; i < (TILE_H + 6) * (TILE_W / 4); i += 256) {
-    int r = i >> 5, c = i & 31;
-    const unsigned *row = &tile[r * TILE_DW + c];
-    unsigned long long lo = row[0] | ((unsigned long long)row[1] << 32);
-    unsigned hi = row[2];
-    // bytes 0..11 of the window = columns 4c-4 .. 4c+7 (relative to x0); pixel p centre = byte 4+p
-    unsigned b[12];
 #pragma unroll
-    for (int k = 0; k < 8; k++) b[k] = (unsigned)(lo >> (8 * k)) & 255u;
-#pragma unroll
-    for (int k = 0; k < 4; k++) b[8 + k] = (hi >> (8 * k)) & 255u;
-    unsigned hv[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      hv[p] = 18u * (b[p + 1] + b[p + 7]) + 34u * (b[p + 2] + b[p + 6]) + 48u * (b[p + 3] + b[p + 5]) + 56u * b[p + 4];
+    for (int k = 0; k < NLD; k++) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < BT_ROWS * TILE_DW) tile[i] = v[k];
     }
-    uint2 w2 = make_uint2(hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16));
-    *reinterpret_cast<uint2 *>(&hbuf[r * TILE_W + 4 * c]) = w2;
   }
   __syncthreads();
 
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  // horizontal pass: task = (row pair, 4-pixel group)
+  for (int i = threadIdx.x; i < BT_PAIRS * (TILE_W / 4); i += 256) {
+    const int rp = i >> 5, c = i & 31;
+    unsigned w0[3], w1[3];
 #pragma unroll
-  for (int half = 0; half < 2; half++) {
-    const int ry = ty + 8 * half;
+    for (int q = 0; q < 3; q++) {
+      w0[q] = tile[(2 * rp) * TILE_DW + c + q];
+      w1[q] = tile[(2 * rp + 1) * TILE_DW + c + q];
+    }
+    // window bytes 0..11 = columns 4c-4 .. 4c+7 (relative to x0); pixel p has its centre at byte 4+p, first tap 1+p
+    const unsigned a01 = as_u32(hblur_pair<1>(w0)), a23 = as_u32(hblur_pair<3>(w0));
+    const unsigned b01 = as_u32(hblur_pair<1>(w1)), b23 = as_u32(hblur_pair<3>(w1));
+    uint4 o;
+    o.x = __builtin_amdgcn_perm(b01, a01, 0x05040100u);  // pixel 0: (row 2rp, row 2rp+1)
+    o.y = __builtin_amdgcn_perm(b01, a01, 0x07060302u);  // pixel 1
+    o.z = __builtin_amdgcn_perm(b23, a23, 0x05040100u);
+    o.w = __builtin_amdgcn_perm(b23, a23, 0x07060302u);
+    *reinterpret_cast<uint4 *>(&hbuf[rp * TILE_W + 4 * c]) = o;
+  }
+  __syncthreads();
+
+  // vertical pass: staged rows ry .. ry+6 of output row ry.  Even ry: pairs (ry,ry+1)(ry+2,ry+3)(ry+4,ry+5)(ry+6,-);
+  // odd ry: (-,ry)(ry+1,ry+2)(ry+3,ry+4)(ry+5,ry+6).  dot2 = a.lo*b.lo + a.hi*b.hi + c with a.lo = even staged row.
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const bool odd = ty & 1;
+  const u16x2 wt0 = odd ? u16x2{0, 18} : u16x2{18, 34};
+  const u16x2 wt1 = odd ? u16x2{34, 48} : u16x2{48, 56};
+  const u16x2 wt2 = odd ? u16x2{56, 48} : u16x2{48, 34};
+  const u16x2 wt3 = odd ? u16x2{34, 18} : u16x2{18, 0};
+#pragma unroll
+  for (int part = 0; part < BT_H / 8; part++) {
+    const int ry = ty + 8 * part;
     const int y = y0 + ry, x = x0 + 4 * tx;
     if (y >= L.h || x >= L.pitch) continue;
-    unsigned acc[4] = {32768u, 32768u, 32768u, 32768u};
-    const unsigned kw[7] = {18u, 34u, 48u, 56u, 48u, 34u, 18u};
-#pragma unroll
-    for (int j = 0; j < 7; j++) {
-      uint2 hv = *reinterpret_cast<const uint2 *>(&hbuf[(ry + j) * TILE_W + 4 * tx]);
-      acc[0] += kw[j] * (hv.x & 0xffffu);
-      acc[1] += kw[j] * (hv.x >> 16);
-      acc[2] += kw[j] * (hv.y & 0xffffu);
-      acc[3] += kw[j] * (hv.y >> 16);
-    }
+    const int rp0 = ry >> 1;
+    const uint4 p0 = *reinterpret_cast<const uint4 *>(&hbuf[(rp0 + 0) * TILE_W + 4 * tx]);
+    const uint4 p1 = *reinterpret_cast<const uint4 *>(&hbuf[(rp0 + 1) * TILE_W + 4 * tx]);
+    const uint4 p2 = *reinterpret_cast<const uint4 *>(&hbuf[(rp0 + 2) * TILE_W + 4 * tx]);
+    const uint4 p3 = *reinterpret_cast<const uint4 *>(&hbuf[(rp0 + 3) * TILE_W + 4 * tx]);
+    const unsigned q0[4] = {p0.x, p0.y, p0.z, p0.w}, q1[4] = {p1.x, p1.y, p1.z, p1.w};
+    const unsigned q2[4] = {p2.x, p2.y, p2.z, p2.w}, q3[4] = {p3.x, p3.y, p3.z, p3.w};
     unsigned out = 0;
 #pragma unroll
-    for (int p = 0; p < 4; p++)
-      if (x + p < L.w) out |= (acc[p] >> 16) << (8 * p);
+    for (int p = 0; p < 4; p++) {
+      unsigned acc = __builtin_amdgcn_udot2(as_u16x2(q0[p]), wt0, 32768u, false);
+      acc = __builtin_amdgcn_udot2(as_u16x2(q1[p]), wt1, acc, false);
+      acc = __builtin_amdgcn_udot2(as_u16x2(q2[p]), wt2, acc, false);
+      acc = __builtin_amdgcn_udot2(as_u16x2(q3[p]), wt3, acc, false);
+      if (x + p < L.w) out |= (acc >> 16) << (8 * p);
+    }
     *reinterpret_cast<unsigned *>(blur + base + (size_t)y * L.pitch + x) = out;
   }
 }
@@ -216,6 +267,6 @@ void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level) {
 }
 
 void launch_blur(const orbgpu_ctx *c, int n_frames) {
-  dim3 grid(c->geom.tiles_per_frame, n_frames);
+  dim3 grid(c->geom.ftiles_per_frame, n_frames);
   hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_blur, c->geom);
 }
