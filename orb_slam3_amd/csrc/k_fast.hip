@@ -8,12 +8,12 @@
 #include <cstdlib>
 
 #include "orbgpu_internal.h"
+#include "tile_stage.hpp"
 
 namespace {
 
 constexpr int TILE_W = 128;
-constexpr int TILE_H = 16;
-constexpr int TILE_DW = TILE_W / 4 + 2;
+constexpr int TILE_DW = STAGE_DW;
 
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
@@ -113,25 +113,8 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
   if (threadIdx.x == 0) q_count = 0;
 #pragma unroll
   for (int k = 0; k < FT_H * TILE_W / 4 / 256; k++) out_tile[threadIdx.x + 256 * k] = 0;
-  {
-    // 38 x 34 dwords; pixels outside the image are never part of a scored ring
-    constexpr int NLD = (FT_ROWS * TILE_DW + 255) / 256;
-    unsigned v[NLD];
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const int i = threadIdx.x + 256 * k;
-      const int r = i / TILE_DW, c = i - r * TILE_DW;
-      const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * c;
-      v[k] = 0;
-      if (i < FT_ROWS * TILE_DW && gy >= 0 && gy < L.h && gx >= 0 && gx < L.pitch)
-        v[k] = *reinterpret_cast<const unsigned *>(src + (size_t)gy * L.pitch + gx);
-    }
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const int i = threadIdx.x + 256 * k;
-      if (i < FT_ROWS * TILE_DW) tile[i] = v[k];
-    }
-  }
+  // 38 x 34 dwords; pixels outside the image are never part of a scored ring
+  stage_tile<FT_ROWS, false>(tile, src, L.w, L.h, L.pitch, x0, y0);
   __syncthreads();
 
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -139,6 +122,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
   const int min_thr = g.fast_min;
   const u16x2 thr2 = {(unsigned short)min_thr, (unsigned short)min_thr};
   // ---- phase 1: packed quick test -------------------------------------------------------------
+  unsigned mask16 = 0;
 #pragma unroll 1
   for (int part = 0; part < FT_H / 8; part++) {
     const int ry = ty + 8 * part;
@@ -188,23 +172,29 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
       for (int p = 0; p < 4; p++)
         if (x + p < 3 || x + p > L.w - 4) mask &= ~(1u << p);
     }
-    // wave-aggregated push: one LDS atomic per wave and iteration
-    unsigned long long b[4];
+    mask16 |= mask << (4 * part);
+  }
+  // ---- push the survivors: one LDS atomic per wave; the order inside the queue does not matter -----
+  {
+    const int cnt = __popc(mask16);  // 0..16
+    int before = 0;                  // survivors of lower lanes: sum over the bits of cnt of popc(ballot & below)
     int tot = 0;
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-      b[p] = __ballot((mask >> p) & 1u);
-      tot += __popcll(b[p]);
+    for (int b = 0; b < 5; b++) {
+      const unsigned long long bal = __ballot((cnt >> b) & 1);
+      before += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u)) << b;
+      tot += __popcll(bal) << b;
     }
     if (tot) {
       int basep = 0;
       if (lane == 0) basep = atomicAdd(&q_count, tot);
-      basep = __shfl(basep, 0);
-      const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-      for (int p = 0; p < 4; p++) {
-        if ((mask >> p) & 1u) queue[basep + __popcll(b[p] & below)] = (unsigned short)(ry * TILE_W + 4 * tx + p);
-        basep += __popcll(b[p]);
+      int pos = __shfl(basep, 0) + before;
+      const int idx0 = ty * TILE_W + 4 * tx;  // bit 4*part + p  ->  pixel (ty + 8*part, 4*tx + p)
+      unsigned m = mask16;
+      while (m) {
+        const int bit = __ffs(m) - 1;
+        m &= m - 1;
+        queue[pos++] = (unsigned short)(idx0 + (bit >> 2) * (8 * TILE_W) + (bit & 3));
       }
     }
   }

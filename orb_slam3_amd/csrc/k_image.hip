@@ -4,12 +4,12 @@
 // Reference stages: BuildImagePyramid  src/features/orb_feature_extractor.cpp:504-528 (cv::resize :517)
 //                   blur in Extract    src/features/orb_feature_extractor.cpp:558-560 (cv::GaussianBlur)
 #include "orbgpu_internal.h"
+#include "tile_stage.hpp"
 
 namespace {
 
 constexpr int TILE_W = 128;  // output pixels per tile row (32 lanes x 4 px: one LDS row per half-wave)
-constexpr int TILE_H = 16;
-constexpr int TILE_DW = TILE_W / 4 + 2;  // dwords per staged row: 4-px apron left and right
+constexpr int TILE_DW = STAGE_DW;  // dwords per staged row: 4-px apron left and right
 
 __device__ __forceinline__ int reflect101(int i, int n) {
   // BORDER_REFLECT_101: -i -> i, (n-1)+i -> (n-1)-i ; the aprons used here are < n
@@ -47,15 +47,29 @@ __global__ __launch_bounds__(256) void k_import(const uint8_t *__restrict__ src,
 // pyramid level l from level l-1.  Integer arithmetic of OpenCV's VResizeLinear/HResizeLinear for 8U:
 //   H = S[sx]*a0 + S[sx+1]*a1 ; dst = (((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2
 // The coefficient tables come from the host (exact float/double sequence).
-// One workgroup produces a 128 x 8 output tile; the two source-row bands it needs (at most
-// ceil(8*1.2)+2 rows of at most 128*1.2+2 bytes) are staged in LDS with coalesced row loads.
-constexpr int RS_TILE_H = 8;
-constexpr int RS_MAX_ROWS = 24;   // source rows staged per tile (scale <= 2.5)
-constexpr int RS_MAX_COLS = 336;  // source bytes staged per row (scale <= 2.5), multiple of 16
+// One workgroup produces a 128 x 32 output tile; its source footprint (rows sy0(first)..sy1(last), columns from the
+// 16-byte boundary below sx0(first) to sx0(last)+1) is staged in dynamic LDS whose size the host derives from the
+// same tables (rs_pitch x rs_rows), so there is no un-staged path.  A lane owns 4 columns x 4 rows: the column
+// coefficients are loaded once and reused for the 4 rows.  Where sx1 clamps to the last column its weight is 0, so
+// the kernel always reads column sx0+1 of the staged row.
+constexpr int RS_TILE_H = 32;
+
+// full-rate 24-bit multiplies, pinned: the optimiser otherwise widens them to the quarter-rate v_mul_lo_u32
+__device__ __forceinline__ unsigned mul24u(unsigned a, unsigned b) {
+  unsigned d;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ unsigned mad24u(unsigned a, unsigned b, unsigned c) {
+  unsigned d;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 
 __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr, DeviceGeom g, int level,
-                                                      const XTab *__restrict__ xtab, const YTab *__restrict__ ytab) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[RS_MAX_ROWS * RS_MAX_COLS];
+                                                      const XTab *__restrict__ xtab, const YTab *__restrict__ ytab,
+                                                      int lds_pitch) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t rs_lds[];
   const LevelGeom S = g.lv[level - 1], D = g.lv[level];
   const int f = blockIdx.z;
   const uint8_t *src = pyr + (size_t)f * g.frame_bytes + S.off;
@@ -65,51 +79,63 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 
   const int dx0 = blockIdx.x * TILE_W, dy0 = blockIdx.y * RS_TILE_H;
   const int dx1 = min(dx0 + TILE_W, D.w) - 1, dy1 = min(dy0 + RS_TILE_H, D.h) - 1;
-  // source footprint of the tile (tables are monotone)
-  const int sxa = xt[dx0].sx0 & ~15;  // 16-byte aligned start
-  const int sxb = xt[dx1].sx1;
+  // source footprint of the tile (tables are monotone); wave-uniform, read through the scalar cache
+  const int sxa = xt[dx0].sx0 & ~15;
+  const int sxb = xt[dx1].sx0 + 1;
   const int sya = yt[dy0].sy0, syb = yt[dy1].sy1;
   const int ncols16 = (sxb - sxa) / 16 + 1;
   const int nrows = syb - sya + 1;
-  const bool fits = ncols16 * 16 <= RS_MAX_COLS && nrows <= RS_MAX_ROWS;
-  if (fits) {
+  {
+    // pitch is a multiple of 16 and slabs are padded, so the 16-byte reads stay inside the slab
+    const float inv = 1.0f / (float)ncols16;
     for (int i = threadIdx.x; i < nrows * ncols16; i += 256) {
-      int r = i / ncols16, c = i - r * ncols16;
-      // pitch is a multiple of 16 and slabs are padded, so the 16-byte read stays inside the slab
-      uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)(sya + r) * S.pitch + sxa + 16 * c);
-      *reinterpret_cast<uint4 *>(&lds[r * RS_MAX_COLS + 16 * c]) = v;
+      int r = (int)((float)i * inv);  // i < 2^15: at most one off, fixed below
+      int c = i - r * ncols16;
+      if (c < 0) { r--; c += ncols16; }
+      if (c >= ncols16) { r++; c -= ncols16; }
+      const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)(sya + r) * S.pitch + sxa + 16 * c);
+      *reinterpret_cast<uint4 *>(&rs_lds[r * lds_pitch + 16 * c]) = v;
     }
   }
-  __syncthreads();
-
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads, 4 px each
-  const int dy = dy0 + ty;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads, 4 columns x 4 rows each
   const int dx = dx0 + 4 * tx;
-  if (dy >= D.h || dx >= D.pitch) return;
-  const YTab Y = yt[dy];
-  unsigned out = 0;
+  // column coefficients (clamped index: columns >= w are computed but masked out of the store)
+  int cx[4];
+  unsigned ca0[4], ca1[4];
 #pragma unroll
   for (int p = 0; p < 4; p++) {
-    int x = dx + p;
-    if (x < D.w) {
-      const XTab X = xt[x];
-      int s00, s01, s10, s11;
-      if (fits) {
-        const int r0 = (Y.sy0 - sya) * RS_MAX_COLS - sxa;
-        const int r1 = (Y.sy1 - sya) * RS_MAX_COLS - sxa;
-        s00 = lds[r0 + X.sx0]; s01 = lds[r0 + X.sx1]; s10 = lds[r1 + X.sx0]; s11 = lds[r1 + X.sx1];
-      } else {
-        const uint8_t *r0 = src + (size_t)Y.sy0 * S.pitch;
-        const uint8_t *r1 = src + (size_t)Y.sy1 * S.pitch;
-        s00 = r0[X.sx0]; s01 = r0[X.sx1]; s10 = r1[X.sx0]; s11 = r1[X.sx1];
-      }
-      int h0 = s00 * X.a0 + s01 * X.a1;
-      int h1 = s10 * X.a0 + s11 * X.a1;
-      int v = ((((int)Y.b0 * (h0 >> 4)) >> 16) + (((int)Y.b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-      out |= (unsigned)(v & 255) << (8 * p);
-    }
+    const XTab X = xt[min(dx + p, D.w - 1)];
+    cx[p] = X.sx0 - sxa;
+    ca0[p] = X.a0;
+    ca1[p] = X.a1;
   }
-  *reinterpret_cast<unsigned *>(dst + (size_t)dy * D.pitch + dx) = out;
+  YTab Y[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) Y[k] = yt[min(dy0 + ty + 8 * k, D.h - 1)];
+  unsigned keep = 0;
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+    if (dx + p < D.w) keep |= 0xffu << (8 * p);
+  __syncthreads();
+  if (dx >= D.pitch) return;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int dy = dy0 + ty + 8 * k;
+    if (dy >= D.h) break;
+    const uint8_t *r0 = rs_lds + mul24u(Y[k].sy0 - sya, lds_pitch);
+    const uint8_t *r1 = rs_lds + mul24u(Y[k].sy1 - sya, lds_pitch);
+    const unsigned b0 = (unsigned)Y[k].b0, b1 = (unsigned)Y[k].b1;  // all coefficients are in [0, 2048]
+    unsigned out = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const unsigned s00 = r0[cx[p]], s01 = r0[cx[p] + 1], s10 = r1[cx[p]], s11 = r1[cx[p] + 1];
+      const unsigned h0 = mad24u(s01, ca1[p], mul24u(s00, ca0[p]));
+      const unsigned h1 = mad24u(s11, ca1[p], mul24u(s10, ca0[p]));
+      const unsigned v = ((mul24u(b0, h0 >> 4) >> 16) + (mul24u(b1, h1 >> 4) >> 16) + 2) >> 2;
+      out |= (v & 255u) << (8 * p);
+    }
+    *reinterpret_cast<unsigned *>(dst + (size_t)dy * D.pitch + dx) = out & keep;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -164,36 +190,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   const size_t base = (size_t)blockIdx.y * g.frame_bytes + L.off;
   const uint8_t *src = pyr + base;
 
-  {
-    constexpr int NLD = (BT_ROWS * TILE_DW + 255) / 256;
-    unsigned v[NLD];
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const int i = threadIdx.x + 256 * k;
-      v[k] = 0;
-      if (i < BT_ROWS * TILE_DW) {
-        const int r = i / TILE_DW, c = i - r * TILE_DW;
-        // rows below the image only feed output rows that are not written; keep the index in range
-        const int gy = reflect101(min(y0 - 3 + r, L.h + 2), L.h);
-        const int gx = x0 - 4 + 4 * c;
-        if (gx >= 0 && gx + 3 < L.w) {
-          v[k] = *reinterpret_cast<const unsigned *>(src + (size_t)gy * L.pitch + gx);
-        } else {
-#pragma unroll
-          for (int b = 0; b < 4; b++) {
-            // columns further than the 3-px apron from the image are never used; the clamp keeps them in range
-            const int xx = reflect101(max(min(gx + b, L.w + 2), -3), L.w);
-            v[k] |= (unsigned)src[(size_t)gy * L.pitch + xx] << (8 * b);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NLD; k++) {
-      const int i = threadIdx.x + 256 * k;
-      if (i < BT_ROWS * TILE_DW) tile[i] = v[k];
-    }
-  }
+  stage_tile<BT_ROWS, true>(tile, src, L.w, L.h, L.pitch, x0, y0);
   __syncthreads();
 
   // horizontal pass: task = (row pair, 4-pixel group)
@@ -225,6 +222,10 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   const u16x2 wt1 = odd ? u16x2{34, 48} : u16x2{48, 56};
   const u16x2 wt2 = odd ? u16x2{56, 48} : u16x2{48, 34};
   const u16x2 wt3 = odd ? u16x2{34, 18} : u16x2{18, 0};
+  unsigned keep = 0;  // bytes of this lane's dword that are image pixels
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+    if (x0 + 4 * tx + p < L.w) keep |= 0xffu << (8 * p);
 #pragma unroll
   for (int part = 0; part < BT_H / 8; part++) {
     const int ry = ty + 8 * part;
@@ -237,15 +238,18 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const uint4 p3 = *reinterpret_cast<const uint4 *>(&hbuf[(rp0 + 3) * TILE_W + 4 * tx]);
     const unsigned q0[4] = {p0.x, p0.y, p0.z, p0.w}, q1[4] = {p1.x, p1.y, p1.z, p1.w};
     const unsigned q2[4] = {p2.x, p2.y, p2.z, p2.w}, q3[4] = {p3.x, p3.y, p3.z, p3.w};
-    unsigned out = 0;
+    unsigned acc[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      unsigned acc = __builtin_amdgcn_udot2(as_u16x2(q0[p]), wt0, 32768u, false);
-      acc = __builtin_amdgcn_udot2(as_u16x2(q1[p]), wt1, acc, false);
-      acc = __builtin_amdgcn_udot2(as_u16x2(q2[p]), wt2, acc, false);
-      acc = __builtin_amdgcn_udot2(as_u16x2(q3[p]), wt3, acc, false);
-      if (x + p < L.w) out |= (acc >> 16) << (8 * p);
+      acc[p] = __builtin_amdgcn_udot2(as_u16x2(q0[p]), wt0, 32768u, false);
+      acc[p] = __builtin_amdgcn_udot2(as_u16x2(q1[p]), wt1, acc[p], false);
+      acc[p] = __builtin_amdgcn_udot2(as_u16x2(q2[p]), wt2, acc[p], false);
+      acc[p] = __builtin_amdgcn_udot2(as_u16x2(q3[p]), wt3, acc[p], false);
     }
+    // acc < 2^24: the result pixel is byte 2 of each accumulator
+    const unsigned lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
+    const unsigned hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0602u);
+    const unsigned out = (lo | (hi << 16)) & keep;
     *reinterpret_cast<unsigned *>(blur + base + (size_t)y * L.pitch + x) = out;
   }
 }
@@ -263,7 +267,9 @@ void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t fr
 void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level) {
   const LevelGeom &D = c->geom.lv[level];
   dim3 grid((D.w + TILE_W - 1) / TILE_W, (D.h + RS_TILE_H - 1) / RS_TILE_H, n_frames);
-  hipLaunchKernelGGL(k_resize_level, grid, dim3(256), 0, c->stream, c->d_pyr, c->geom, level, c->d_xtab, c->d_ytab);
+  const size_t lds = (size_t)c->rs_pitch[level] * c->rs_rows[level];
+  hipLaunchKernelGGL(k_resize_level, grid, dim3(256), lds, c->stream, c->d_pyr, c->geom, level, c->d_xtab, c->d_ytab,
+                     c->rs_pitch[level]);
 }
 
 void launch_blur(const orbgpu_ctx *c, int n_frames) {

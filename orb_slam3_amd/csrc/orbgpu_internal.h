@@ -63,6 +63,7 @@ struct orbgpu_ctx {
   DeviceGeom geom{};
   double scale[ORBGPU_MAX_LEVELS]{}, inv_scale[ORBGPU_MAX_LEVELS]{}, sigma2[ORBGPU_MAX_LEVELS]{};
   int nini[ORBGPU_MAX_LEVELS]{};
+  int rs_pitch[ORBGPU_MAX_LEVELS]{}, rs_rows[ORBGPU_MAX_LEVELS]{};  // LDS footprint of a resize tile (bytes per row, rows)
   int device = 0;
   hipStream_t stream = nullptr;
   std::mutex mu;
