@@ -7,6 +7,7 @@
 #include <cfloat>
 
 #include "orbgpu_internal.h"
+#include "tile_stage.hpp"
 
 namespace {
 
@@ -60,18 +61,19 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
                                                          const int *__restrict__ kp_count,
                                                          orbgpu_keypoint *__restrict__ out_kp,
                                                          uint8_t *__restrict__ out_desc, int capacity,
-                                                         int *__restrict__ out_n) {
+                                                         int *__restrict__ out_n, int n_frames) {
   __shared__ unsigned patch[KPB][PW * PDW];
   __shared__ float s_angle[KPB];
   __shared__ float s_cs[KPB][2];
-  const int f = blockIdx.y;
+  int f, group;
+  if (!xcd_item_frame((g.kps_per_frame + KPB - 1) / KPB, n_frames, group, f)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int slot = blockIdx.x * KPB + wave;
+  const int slot = group * KPB + wave;
   const int *cnt = kp_count + f * g.levels;
   // total and per-level prefix (<= 16 levels; every lane computes the same scalars)
   int total = 0;
   for (int l = 0; l < g.levels; l++) total += cnt[l];
-  if (blockIdx.x == 0 && threadIdx.x == 0) out_n[f] = total;
+  if (group == 0 && threadIdx.x == 0) out_n[f] = total;
   // validity is wave-uniform; invalid waves only take part in the barriers
   bool valid = slot < g.kps_per_frame && total <= capacity;
   int l = 0;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
 
 void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                             int *d_n_out) {
-  dim3 grid((c->geom.kps_per_frame + KPB - 1) / KPB, n_frames);
+  dim3 grid((c->geom.kps_per_frame + KPB - 1) / KPB * xcd_frames(n_frames));
   hipLaunchKernelGGL(k_orient_describe, grid, dim3(64 * KPB), 0, c->stream, c->d_pyr, c->d_blur, c->geom, c->d_kp_xy,
-                     c->d_kp_count, d_kp, d_desc, capacity, d_n_out);
+                     c->d_kp_count, d_kp, d_desc, capacity, d_n_out, n_frames);
 }

@@ -95,19 +95,20 @@ constexpr int FT_H = 32;                 // FAST tile: 128 x 32 pixels, 256 thre
 constexpr int FT_ROWS = FT_H + 6;
 
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score,
-                                                    DeviceGeom g) {
+                                                    DeviceGeom g, int n_frames) {
   __shared__ unsigned tile[FT_ROWS * TILE_DW];
   __shared__ unsigned out_tile[FT_H * TILE_W / 4];
   __shared__ unsigned short queue[FT_H * TILE_W];
   __shared__ int q_count;
-  int t = blockIdx.x, l = 0;
+  int t, frame, l = 0;
+  if (!xcd_item_frame(g.ftiles_per_frame, n_frames, t, frame)) return;
 #pragma unroll 1
   while (l + 1 < g.levels && t >= g.lv[l + 1].ftile_off) l++;
   const LevelGeom L = g.lv[l];
   t -= L.ftile_off;
   const int tiles_x = (L.w + TILE_W - 1) / TILE_W;
   const int x0 = (t % tiles_x) * TILE_W, y0 = (t / tiles_x) * FT_H;
-  const size_t base = (size_t)blockIdx.y * g.frame_bytes + L.off;
+  const size_t base = (size_t)frame * g.frame_bytes + L.off;
   const uint8_t *src = pyr + base;
 
   if (threadIdx.x == 0) q_count = 0;
@@ -242,7 +243,7 @@ constexpr int CELLS_PER_WG = 4;
 
 __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t *__restrict__ score, DeviceGeom g,
                                                                    CellEntry *__restrict__ cells,
-                                                                   unsigned *__restrict__ cands) {
+                                                                   unsigned *__restrict__ cands, int n_frames) {
   __shared__ unsigned s32_all[CELLS_PER_WG][CELL_MAX * CELL_DW];
   __shared__ unsigned short queue_all[CELLS_PER_WG][CQ_CAP];
   __shared__ unsigned long long m_hi_all[CELLS_PER_WG][CELL_MAX], m_lo_all[CELLS_PER_WG][CELL_MAX];
@@ -251,8 +252,9 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
   const uint8_t *s8 = reinterpret_cast<const uint8_t *>(s32);
   unsigned short *queue = queue_all[wave];
   unsigned long long *m_hi = m_hi_all[wave], *m_lo = m_lo_all[wave];
-  const int f = blockIdx.y;
-  int c = blockIdx.x * CELLS_PER_WG + wave, l = 0;
+  int f, c, l = 0;
+  if (!xcd_item_frame((g.cells_per_frame + CELLS_PER_WG - 1) / CELLS_PER_WG, n_frames, c, f)) return;
+  c = c * CELLS_PER_WG + wave;
   if (c >= g.cells_per_frame) return;
 #pragma unroll 1
   while (l + 1 < g.levels && c >= g.lv[l + 1].cell_off) l++;
@@ -391,11 +393,12 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
 }  // namespace
 
 void launch_fast_score(const orbgpu_ctx *c, int n_frames) {
-  dim3 grid(c->geom.ftiles_per_frame, n_frames);
-  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_score, c->geom);
+  dim3 grid(c->geom.ftiles_per_frame * xcd_frames(n_frames));
+  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_score, c->geom, n_frames);
 }
 
 void launch_cell_detect(const orbgpu_ctx *c, int n_frames) {
-  dim3 grid((c->geom.cells_per_frame + CELLS_PER_WG - 1) / CELLS_PER_WG, n_frames);
-  hipLaunchKernelGGL(k_cell_detect, grid, dim3(64 * CELLS_PER_WG), 0, c->stream, c->d_score, c->geom, c->d_cells, c->d_cands);
+  dim3 grid((c->geom.cells_per_frame + CELLS_PER_WG - 1) / CELLS_PER_WG * xcd_frames(n_frames));
+  hipLaunchKernelGGL(k_cell_detect, grid, dim3(64 * CELLS_PER_WG), 0, c->stream, c->d_score, c->geom, c->d_cells, c->d_cands,
+                     n_frames);
 }

@@ -68,16 +68,19 @@ __device__ __forceinline__ unsigned mad24u(unsigned a, unsigned b, unsigned c) {
 
 __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr, DeviceGeom g, int level,
                                                       const XTab *__restrict__ xtab, const YTab *__restrict__ ytab,
-                                                      int lds_pitch) {
+                                                      int lds_pitch, int n_frames) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rs_lds[];
   const LevelGeom S = g.lv[level - 1], D = g.lv[level];
-  const int f = blockIdx.z;
+  const int tiles_x = (D.w + TILE_W - 1) / TILE_W, tiles_y = (D.h + RS_TILE_H - 1) / RS_TILE_H;
+  int t, f;
+  if (!xcd_item_frame(tiles_x * tiles_y, n_frames, t, f)) return;
+  const int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
   const uint8_t *src = pyr + (size_t)f * g.frame_bytes + S.off;
   uint8_t *dst = pyr + (size_t)f * g.frame_bytes + D.off;
   const XTab *xt = xtab + D.xtab_off;
   const YTab *yt = ytab + D.ytab_off;
 
-  const int dx0 = blockIdx.x * TILE_W, dy0 = blockIdx.y * RS_TILE_H;
+  const int dx0 = tile_x * TILE_W, dy0 = tile_y * RS_TILE_H;
   const int dx1 = min(dx0 + TILE_W, D.w) - 1, dy1 = min(dy0 + RS_TILE_H, D.h) - 1;
   // source footprint of the tile (tables are monotone); wave-uniform, read through the scalar cache
   const int sxa = xt[dx0].sx0 & ~15;
@@ -176,18 +179,20 @@ __device__ __forceinline__ u16x2 hblur_pair(const unsigned (&w)[3]) {
   return s0 * k18 + s1 * k34 + s2 * k48 + pair_bytes<B + 3>(w) * k56;
 }
 
-__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g) {
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g,
+                                              int n_frames) {
   __shared__ unsigned tile[BT_ROWS * TILE_DW];
   __shared__ __attribute__((aligned(16))) unsigned hbuf[BT_PAIRS * TILE_W];  // (h[2m][x], h[2m+1][x]) per dword
   // tile -> (level, tile x, tile y)
-  int t = blockIdx.x, l = 0;
+  int t, frame, l = 0;
+  if (!xcd_item_frame(g.ftiles_per_frame, n_frames, t, frame)) return;
 #pragma unroll 1
   while (l + 1 < g.levels && t >= g.lv[l + 1].ftile_off) l++;
   const LevelGeom L = g.lv[l];
   t -= L.ftile_off;
   const int tiles_x = (L.w + TILE_W - 1) / TILE_W;
   const int x0 = (t % tiles_x) * TILE_W, y0 = (t / tiles_x) * BT_H;
-  const size_t base = (size_t)blockIdx.y * g.frame_bytes + L.off;
+  const size_t base = (size_t)frame * g.frame_bytes + L.off;
   const uint8_t *src = pyr + base;
 
   stage_tile<BT_ROWS, true>(tile, src, L.w, L.h, L.pitch, x0, y0);
@@ -266,13 +271,13 @@ void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t fr
 
 void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level) {
   const LevelGeom &D = c->geom.lv[level];
-  dim3 grid((D.w + TILE_W - 1) / TILE_W, (D.h + RS_TILE_H - 1) / RS_TILE_H, n_frames);
+  dim3 grid(((D.w + TILE_W - 1) / TILE_W) * ((D.h + RS_TILE_H - 1) / RS_TILE_H) * xcd_frames(n_frames));
   const size_t lds = (size_t)c->rs_pitch[level] * c->rs_rows[level];
   hipLaunchKernelGGL(k_resize_level, grid, dim3(256), lds, c->stream, c->d_pyr, c->geom, level, c->d_xtab, c->d_ytab,
-                     c->rs_pitch[level]);
+                     c->rs_pitch[level], n_frames);
 }
 
 void launch_blur(const orbgpu_ctx *c, int n_frames) {
-  dim3 grid(c->geom.ftiles_per_frame, n_frames);
-  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_blur, c->geom);
+  dim3 grid(c->geom.ftiles_per_frame * xcd_frames(n_frames));
+  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_blur, c->geom, n_frames);
 }

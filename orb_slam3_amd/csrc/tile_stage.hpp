@@ -8,6 +8,20 @@
 
 #include <cstdint>
 
+// XCD-aware work order for the (item, frame) grids.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs and
+// each XCD has its own L2, so XCD k is given whole frames (k, k+8, ...) and walks each frame's items in order: tiles
+// that share apron cache lines, and the cells / keypoints that re-read them, then meet in one L2.
+// Launch a 1-D grid of items_per_frame * xcd_frames(n_frames) workgroups.
+inline int xcd_frames(int n_frames) { return (n_frames + 7) & ~7; }
+__device__ __forceinline__ bool xcd_item_frame(int items_per_frame, int n_frames, int &item, int &frame) {
+  const unsigned id = blockIdx.x;
+  const unsigned j = id >> 3;
+  const unsigned fq = j / (unsigned)items_per_frame;
+  item = (int)(j - fq * (unsigned)items_per_frame);
+  frame = (int)(fq * 8u + (id & 7u));
+  return frame < n_frames;
+}
+
 constexpr int STAGE_DW = 34;  // dwords per staged row: columns x0-4 .. x0+131
 
 // REFLECT = false: bytes outside the image read as 0 (FAST never scores a ring that touches them).
