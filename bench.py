@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--features", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true")
+    ap.add_argument("--no-allpairs", action="store_true", help="skip the keyframe all-pairs section (SURVEY 8e)")
+    ap.add_argument("--keyframe-every", type=int, default=4)
     args = ap.parse_args()
 
     import torch
@@ -115,6 +117,40 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
+    # ---- SURVEY 8e / BASELINE.json configs[4]: cross-shard all-pairs keyframe matching -------------------------
+    # every rank all-gathers the keyframe descriptor + keypoint shards (the path's ONE exchange step; RCCL when
+    # N > 1) and matches its keyframes against all.  Reported beside the headline value, never part of it.
+    allpairs = None
+    if not args.no_allpairs and B >= args.keyframe_every:
+        from orb_slam3_amd.sharding import match_keyframes_allpairs
+        kf = torch.arange(0, B, args.keyframe_every, device=dev)
+        k_kp, k_desc, k_n = d_kp[kf].contiguous(), d_desc[kf].contiguous(), d_n[kf].contiguous()
+        best = None
+        for it in range(3):
+            barrier()
+            t1 = time.perf_counter()
+            nm, _, off = match_keyframes_allpairs(fe, k_kp, k_desc, k_n, 50, 0.9, True)
+            barrier()
+            dt = time.perf_counter() - t1
+            best = dt if best is None else min(best, dt)
+        tt = torch.tensor([best], dtype=torch.float64, device=dev)
+        n_tot = k_n.to(torch.float64).sum().reshape(1)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(n_tot)
+        k_local = int(kf.numel())
+        # descriptor pairs this job evaluated: every ordered keyframe pair (r, c), r != c: n_r * n_c
+        sq = (k_n.to(torch.float64) ** 2).sum().reshape(1)
+        if world > 1:
+            dist.all_reduce(sq)
+        desc_pairs = float(n_tot.item()) ** 2 - float(sq.item())
+        allpairs = {"keyframes_total": k_local * world, "keyframe_pairs": k_local * world * (k_local * world - 1),
+                    "descriptor_pairs": desc_pairs, "ms": round(float(tt.item()) * 1e3, 3),
+                    "descriptor_pairs_per_s": round(desc_pairs / float(tt.item()), 1),
+                    "allgather_bytes_per_rank": int(k_local * cap * 64 + k_local * 4),
+                    "exchange": "torch.distributed all_gather_into_tensor (RCCL)" if world > 1 else "none (1 rank)",
+                    "matches_rank0": int(nm.sum().item()), "includes": "all-gather + match + rotation filter, max over ranks"}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -128,9 +164,19 @@ def main():
     fast_s = st[1] * 1e-3
     hbm_peak = 8000.0
     fast_gbs = P * B / fast_s / 1e9 if fast_s > 0 else 0.0
+    # HBM-side bytes per launch from the committed counter passes (tools/profile_round.sh -> profiles/): valid for the
+    # default workload only, null otherwise
+    traffic, traffic_src = None, None
+    tfile = ROOT / "profiles" / "r1_hbm_traffic.json"
+    if tfile.exists() and (W, H, NF, B) == (640, 480, 1000, 256):
+        tj = json.loads(tfile.read_text())
+        traffic = tj["kernels"].get("k_fast_score", {}).get("hbm_bytes")
+        traffic_src = "profiles/r1_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this workload)"
     roofline = {"bound": "hbm", "kernel": "k_fast_score", "achieved": round(fast_gbs, 2), "peak": hbm_peak,
-                "unit": "GB/s", "frac": round(fast_gbs / hbm_peak, 5), "traffic": None,
-                "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P * B}
+                "unit": "GB/s", "frac": round(fast_gbs / hbm_peak, 5), "traffic": traffic,
+                "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P * B, "traffic_source": traffic_src,
+                "limiter": "vector-ALU issue, not HBM: ~3.4e3 VALU wave-instructions per 128x32 tile at ~1 per clock per CU "
+                           "(profiles/r1_pmc_sq.txt, profiles/r1_valu_rate.txt)"}
     # whole extraction against SURVEY 8d's per-frame figure A = 5P - px0 - px7 + 1978 N
     A = 5 * P - g.w[0] * g.h[0] - g.w[g.levels - 1] * g.h[g.levels - 1] + 1978 * NF
     ext_s = st[6] * 1e-3
@@ -168,7 +214,7 @@ def main():
                     "n_matched": int((di >= 0).sum().item())}
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         # the oracle (CPU restatement; kind "port") on a bounded sample of the same frames, one core
         from oracle import orb_oracle as oo
         oo.build()
@@ -177,8 +223,8 @@ def main():
         done = 0
         prev = None
         budget_s = 12.0
-        while done < B and time.perf_counter() - t1 < budget_s:
-            k, d = oo.extract_literal(p, frames[done], NF)
+        while time.perf_counter() - t1 < budget_s:   # cycles through the batch until ~12 s of CPU work are done
+            k, d = oo.extract_literal(p, frames[done % B], NF)
             if prev is not None:
                 mf, _ = oo.match_area(k, d, prev[0], prev[1], 100, 50, 0.9)
                 oo.orientation_validate(k["angle"], prev[0]["angle"], mf)
@@ -186,7 +232,7 @@ def main():
             done += 1
         cpu_s = time.perf_counter() - t1
         cpu = {"value": round(done / cpu_s, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"first {done} frames of the same {B}-frame batch: oracle extract (literal cv::FAST) + window link + rotation filter, single thread"}
+               "sample": f"{done} frames drawn in order (cyclically) from the same {B}-frame batch, {cpu_s:.1f} s: oracle extract (literal cv::FAST) + window link + rotation filter, single thread"}
 
     out = {"metric": "frames/sec ORB extract+match (640x480, 8 lvls, 1000 kp); Hamming matches/sec",
            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -196,7 +242,8 @@ def main():
                       "frames_per_gpu": B, "keypoints_mean": round(float(n_kp.mean()), 1),
                       "link_matches_mean": round(float(n_matches.mean()), 1) if n_pairs else 0.0,
                       "parallelism": f"frame-sharded x{world}"},
-           "roofline": roofline, "pipeline": pipeline, "matching": matching, "cpu_baseline": cpu}
+           "roofline": roofline, "pipeline": pipeline, "matching": matching, "keyframe_allpairs": allpairs,
+           "cpu_baseline": cpu}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

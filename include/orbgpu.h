@@ -173,6 +173,24 @@ int orbgpu_match_frames_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp, con
                                double ratio, int32_t check_orientation, int32_t *d_match, uint32_t *d_dist,
                                int32_t *d_n_matches);
 
+/* replaces: loop-candidate / keyframe-to-keyframe matching built on SNNMatcher<It>::MatchWithIterators
+ * (features/matching/second_nearest_neighbor_matcher.hpp:30-80; call shape of MonocularKeyFrame::
+ * FindMatchingMapPoints, frame/monocular/monocular_key_frame.cpp:277-301) in its all-pairs form:
+ * every keyframe r of the row set ('to') against every keyframe c of the column set ('from'), every 'from'
+ * keypoint a candidate in index order, then ratio / threshold / uniqueness and, when check_orientation != 0,
+ * OrientationValidator::Validate (validators/orientation_validator.cpp:16-97).
+ * Both sets are laid out like the output of orbgpu_extract_batch_device: keyframe k occupies rows
+ * [k*capacity, k*capacity + n[k]) of its descriptor (x32 bytes) and keypoint arrays; capacity <= 4096.
+ * row_offset >= 0 names the column index of row 0 when the rows are a slice of the columns (one rank's shard of
+ * an all-gathered set): the pair (r, row_offset + r) is then skipped and reports 0 matches; pass -1 otherwise.
+ * d_n_matches is n_rows x n_cols; d_match (n_rows x n_cols x capacity, 'from' index or -1) may be NULL.
+ * Asynchronous on the context's stream; all pointers are device pointers. */
+int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
+                                 const int32_t *d_n_rows, int32_t n_rows, const orbgpu_keypoint *d_kp_cols,
+                                 const uint8_t *d_desc_cols, const int32_t *d_n_cols, int32_t n_cols, int32_t capacity,
+                                 int32_t row_offset, uint32_t threshold, double ratio, int32_t check_orientation,
+                                 int32_t *d_n_matches, int32_t *d_match);
+
 /* replaces: OrientationValidator::Validate (validators/orientation_validator.cpp:16-97).
  * match[i] >= 0 means 'to' i is matched to 'from' match[i]; discarded matches are set to -1. */
 int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to, const float *angle_from,

@@ -47,7 +47,8 @@ assert KP_DTYPE.itemsize == 32
 EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_geometry", "orbgpu_stream",
            "orbgpu_synchronize", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
            "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_window",
-           "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_rotation_filter", "orbgpu_stage_times",
+           "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_match_allpairs_device",
+           "orbgpu_rotation_filter", "orbgpu_stage_times",
            "orbgpu_popcount_peak"]
 
 _lib = None
@@ -79,6 +80,7 @@ def load():
         "orbgpu_match_window": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_window_device": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_frames_device": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, u64, u32, dbl, i32, vp, vp, vp]),
+        "orbgpu_match_allpairs_device": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, u32, dbl, i32, vp, vp]),
         "orbgpu_rotation_filter": (i32, [vp, vp, i32, vp, i32, vp, C.POINTER(i32)]),
         "orbgpu_stage_times": (i32, [vp, vp]),
         "orbgpu_popcount_peak": (i32, [vp, C.POINTER(dbl)]),
@@ -89,6 +91,12 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def check(rc, handle=None):
+    """Raise OrbGpuError for a non-zero status of a C-ABI call (message from orbgpu_last_error)."""
+    if rc != OK:
+        raise OrbGpuError(rc, load().orbgpu_last_error(handle).decode())
 
 
 def ptr(a):

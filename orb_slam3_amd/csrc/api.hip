@@ -718,6 +718,27 @@ int orbgpu_match_frames_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp, con
   return ORBGPU_OK;
 }
 
+int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
+                                 const int32_t *d_n_rows, int32_t n_rows, const orbgpu_keypoint *d_kp_cols,
+                                 const uint8_t *d_desc_cols, const int32_t *d_n_cols, int32_t n_cols, int32_t capacity,
+                                 int32_t row_offset, uint32_t threshold, double ratio, int32_t check_orientation,
+                                 int32_t *d_n_matches, int32_t *d_match) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (n_rows < 0 || n_cols < 0 || capacity < 1) return fail(ctx, ORBGPU_E_INVALID, "bad size");
+  if (n_rows == 0 || n_cols == 0) return ORBGPU_OK;
+  if (!d_desc_rows || !d_n_rows || !d_desc_cols || !d_n_cols || !d_n_matches) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (check_orientation && (!d_kp_rows || !d_kp_cols))
+    return fail(ctx, ORBGPU_E_INVALID, "check_orientation needs the keypoint arrays of both sets");
+  if (allpairs_lds_bytes(capacity) > 64 * 1024) return fail(ctx, ORBGPU_E_CAPACITY, "capacity above 4096 keypoints per keyframe");
+  if ((uint64_t)n_cols * (uint64_t)((n_rows + 7) & ~7) >= (1ull << 31)) return fail(ctx, ORBGPU_E_INVALID, "too many pairs for one call");
+  HIP_TRY(hipSetDevice(ctx->device));
+  launch_match_allpairs(ctx, d_kp_rows, d_desc_rows, d_n_rows, n_rows, d_kp_cols, d_desc_cols, d_n_cols, n_cols, capacity,
+                        row_offset, threshold, ratio, check_orientation, d_n_matches, d_match);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
 int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to, const float *angle_from, int32_t n_from,
                            int32_t *match, int32_t *n_discarded) {
   if (!ctx) return ORBGPU_E_INVALID;

@@ -13,6 +13,7 @@
 // key orders by distance first and index second, "first candidate wins a tie" (strict < at :50) and
 // "a tie with the best becomes the second best" (:54) fall out of plain unsigned min / median.
 #include "orbgpu_internal.h"
+#include "tile_stage.hpp"
 
 namespace {
 
@@ -376,6 +377,124 @@ __global__ __launch_bounds__(256) void k_link_resolve(const orbgpu_keypoint *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// All-pairs keyframe matching: 'to' = keyframe r of the row set, 'from' = keyframe c of the column set,
+// SNNMatcher::MatchWithIterators semantics with no candidate restriction (every 'from' in index order), then the
+// optional rotation histogram.  One workgroup owns one (r, c) pair from the scan to the match count, so nothing but
+// the count (and, on request, the match list) touches global memory: the per-'from' claims and the per-'to' results
+// live in LDS.  A lane holds AP_T 'to' descriptors, the 'from' descriptors are wave-uniform scalar loads.
+// Work order: XCD k takes rows k, k+8, ... and walks their columns, so a row's descriptors stay in that XCD's L2.
+constexpr int AP_T = 4;
+
+__global__ __launch_bounds__(256) void k_allpairs(const orbgpu_keypoint *__restrict__ kp_rows,
+                                                  const uint8_t *__restrict__ desc_rows, const int *__restrict__ n_rows_kp,
+                                                  int n_rows, const orbgpu_keypoint *__restrict__ kp_cols,
+                                                  const uint8_t *__restrict__ desc_cols, const int *__restrict__ n_cols_kp,
+                                                  int n_cols, int capacity, int row_offset, unsigned threshold,
+                                                  double ratio, int check_orientation, int *__restrict__ n_matches,
+                                                  int *__restrict__ match_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ap_lds[];
+  unsigned long long *claim = reinterpret_cast<unsigned long long *>(ap_lds);  // [capacity] per 'from'
+  int *mj = reinterpret_cast<int *>(claim + capacity);                        // [capacity] per 'to': from index or -1
+  unsigned *md = reinterpret_cast<unsigned *>(mj + capacity);                 // [capacity] per 'to': distance
+  __shared__ int total;
+  int c, r;
+  if (!xcd_item_frame(n_cols, n_rows, c, r)) return;
+  int *out_n = n_matches + (size_t)r * n_cols + c;
+  int *out_m = match_out ? match_out + ((size_t)r * n_cols + c) * capacity : nullptr;
+  const int n_to = min(n_rows_kp[r], capacity), n_from = min(n_cols_kp[c], capacity);
+  if ((row_offset >= 0 && row_offset + r == c) || n_to == 0 || n_from == 0) {  // a keyframe is not matched with itself
+    if (threadIdx.x == 0) *out_n = 0;
+    if (out_m)
+      for (int i = threadIdx.x; i < capacity; i += 256) out_m[i] = -1;
+    return;
+  }
+  for (int j = threadIdx.x; j < n_from; j += 256) claim[j] = ~0ull;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  const uint4 *__restrict__ fd = reinterpret_cast<const uint4 *>(desc_cols + (size_t)c * capacity * 32);
+  const uint4 *__restrict__ tdb = reinterpret_cast<const uint4 *>(desc_rows + (size_t)r * capacity * 32);
+  for (int i0 = 0; i0 < n_to; i0 += 256 * AP_T) {
+    unsigned t[AP_T][8], best[AP_T], second[AP_T];
+    int row[AP_T];
+#pragma unroll
+    for (int q = 0; q < AP_T; q++) {
+      row[q] = i0 + q * 256 + threadIdx.x;
+      const uint4 *td = tdb + 2 * (size_t)min(row[q], n_to - 1);
+      const uint4 t0 = td[0], t1 = td[1];
+      t[q][0] = t0.x; t[q][1] = t0.y; t[q][2] = t0.z; t[q][3] = t0.w;
+      t[q][4] = t1.x; t[q][5] = t1.y; t[q][6] = t1.z; t[q][7] = t1.w;
+      best[q] = second[q] = KEY_NONE;
+    }
+    auto eval = [&](int j, const uint4 &fa, const uint4 &fb) {
+#pragma unroll
+      for (int q = 0; q < AP_T; q++) {
+        const unsigned key = (hamming8(t[q], fa, fb) << IDX_BITS) | (unsigned)j;
+        second[q] = umed3(best[q], key, second[q]);
+        best[q] = min(best[q], key);
+      }
+    };
+    int j = 0;
+    const int jfull = (n_from / SNN_U) * SNN_U;
+    if (j < jfull) {
+      uint4 ca[SNN_U], cb[SNN_U];
+#pragma unroll
+      for (int u = 0; u < SNN_U; u++) {
+        ca[u] = fd[2 * u];
+        cb[u] = fd[2 * u + 1];
+      }
+      for (; j < jfull; j += SNN_U) {
+        uint4 na[SNN_U], nb[SNN_U];
+        const int jn = min(j + SNN_U, jfull - SNN_U);
+#pragma unroll
+        for (int u = 0; u < SNN_U; u++) {
+          na[u] = fd[2 * (jn + u)];
+          nb[u] = fd[2 * (jn + u) + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < SNN_U; u++) eval(j + u, ca[u], cb[u]);
+#pragma unroll
+        for (int u = 0; u < SNN_U; u++) {
+          ca[u] = na[u];
+          cb[u] = nb[u];
+        }
+      }
+    }
+    for (; j < n_from; j++) eval(j, fd[2 * j], fd[2 * j + 1]);
+#pragma unroll
+    for (int q = 0; q < AP_T; q++) {
+      if (row[q] >= n_to) continue;
+      unsigned d = 0;
+      const int jm = snn_accept(best[q], second[q], threshold, ratio, d);
+      mj[row[q]] = jm;
+      md[row[q]] = d;
+      if (jm >= 0) atomicMin(&claim[jm], ((unsigned long long)d << 32) | (unsigned)row[q]);
+    }
+  }
+  __syncthreads();
+  // uniqueness (second_nearest_neighbor_matcher.hpp:57-70): a 'from' keeps its smallest distance, earliest 'to'
+  int cnt = 0;
+  for (int i = threadIdx.x; i < n_to; i += 256) {
+    const int jm = mj[i];
+    if (jm >= 0) {
+      if (claim[jm] != (((unsigned long long)md[i] << 32) | (unsigned)i)) mj[i] = -1;
+      else cnt++;
+    }
+  }
+  if (cnt) atomicAdd(&total, cnt);
+  __syncthreads();
+  if (check_orientation) {
+    const orbgpu_keypoint *kt = kp_rows + (size_t)r * capacity, *kf = kp_cols + (size_t)c * capacity;
+    rotation_filter_block(
+        n_to, mj, [&](int i) { return kt[i].angle; }, [&](int jj) { return kf[jj].angle; }, nullptr, out_n);
+    __syncthreads();
+  } else if (threadIdx.x == 0) {
+    *out_n = total;
+  }
+  if (out_m)
+    for (int i = threadIdx.x; i < capacity; i += 256) out_m[i] = i < n_to ? mj[i] : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // popcount ceiling: the inner loop of snn_scan with the 'from' words synthesised in SGPRs (no memory)
 __global__ __launch_bounds__(256) void k_popcount_peak(unsigned *sink, int iters) {
   unsigned t[8];
@@ -459,6 +578,19 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
                      capacity, d_to_frame, d_from_frame, n_chunks, partial, th, ratio, d_match, d_dist, claim);
   hipLaunchKernelGGL(k_link_resolve, dim3(n_pairs), dim3(256), 0, c->stream, d_kp, d_n, capacity, d_to_frame,
                      d_from_frame, claim, check_orientation, d_match, d_dist, d_n_matches);
+}
+
+size_t allpairs_lds_bytes(int capacity) { return (size_t)capacity * 16; }
+
+void launch_match_allpairs(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
+                           const int *d_n_rows, int n_rows, const orbgpu_keypoint *d_kp_cols, const uint8_t *d_desc_cols,
+                           const int *d_n_cols, int n_cols, int capacity, int row_offset, unsigned threshold, double ratio,
+                           int check_orientation, int *d_n_matches, int *d_match) {
+  const unsigned th = std::min(threshold, 256u);
+  dim3 grid((unsigned)n_cols * (unsigned)xcd_frames(n_rows));
+  hipLaunchKernelGGL(k_allpairs, grid, dim3(256), allpairs_lds_bytes(capacity), c->stream, d_kp_rows, d_desc_rows, d_n_rows,
+                     n_rows, d_kp_cols, d_desc_cols, d_n_cols, n_cols, capacity, row_offset, th, ratio, check_orientation,
+                     d_n_matches, d_match);
 }
 
 void launch_rotation_filter(const orbgpu_ctx *c, const float *d_ang_to, int n_to, const float *d_ang_from, int *d_match,

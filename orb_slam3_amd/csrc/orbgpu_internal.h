@@ -140,6 +140,11 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
                          int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
                          unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,
                          int *d_n_matches);
+size_t allpairs_lds_bytes(int capacity);
+void launch_match_allpairs(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
+                           const int *d_n_rows, int n_rows, const orbgpu_keypoint *d_kp_cols, const uint8_t *d_desc_cols,
+                           const int *d_n_cols, int n_cols, int capacity, int row_offset, unsigned threshold, double ratio,
+                           int check_orientation, int *d_n_matches, int *d_match);
 void launch_rotation_filter(const orbgpu_ctx *c, const float *d_ang_to, int n_to, const float *d_ang_from, int *d_match,
                             int *d_n_discarded);
 double run_popcount_peak(const orbgpu_ctx *c);

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh into per-launch HBM-side byte counts.
+
+Following the MI355X guide's HBM section: the two counters come from separate --pmc passes; on gfx950 FETCH_SIZE
+tallies 128-byte requests as 64 bytes, so it is corrected by the factor measured with tools/hbm_calib.bin on the
+access width these kernels use (one dword per lane; known 1 GiB read and 1 GiB written, far beyond the Infinity
+Cache) -- the factor comes out as 2.0 for FETCH_SIZE and 1.0 for WRITE_SIZE.  Counters are in KiB.
+Usage: pmc_traffic.py gpurun_out/prof_TAG profiles/TAG_hbm_traffic.json"""
+import collections, csv, glob, json, re, sys
+
+root, out = sys.argv[1], sys.argv[2]
+
+
+def mean_per_kernel(sub, counter):
+    acc, n = collections.defaultdict(float), collections.defaultdict(int)
+    for f in glob.glob(f"{root}/{sub}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            m = re.search(r"\bk_\w+", row["Kernel_Name"])
+            if m:
+                acc[m.group(0)] += float(row["Counter_Value"])
+                n[m.group(0)] += 1
+    return {k: acc[k] / n[k] for k in acc}
+
+
+KNOWN = float(1 << 30)
+cf = mean_per_kernel("calib_fetch", "FETCH_SIZE")["k_calib_read"] * 1024
+cw = mean_per_kernel("calib_write", "WRITE_SIZE")["k_calib_write"] * 1024
+f_fetch, f_write = KNOWN / cf, KNOWN / cw
+fetch = mean_per_kernel("pmc_fetch", "FETCH_SIZE")
+write = mean_per_kernel("pmc_write", "WRITE_SIZE")
+res = {"source": f"{root}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 "
+                 "--no-cpu-baseline --no-bruteforce`; mean per launch; KiB counters x 1024 x calibration factor",
+       "calibration": {"fetch_factor": round(f_fetch, 4), "write_factor": round(f_write, 4),
+                       "method": "tools/hbm_calib.bin: 1 GiB dword-per-lane streaming read / write under the same two passes"},
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    fb = fetch.get(k, 0.0) * 1024 * f_fetch
+    wb = write.get(k, 0.0) * 1024 * f_write
+    res["kernels"][k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes": round(fb + wb)}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res["calibration"]), {k: v["hbm_bytes"] for k, v in res["kernels"].items()})

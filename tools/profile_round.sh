@@ -20,4 +20,6 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/calib_write --output-form
 echo calib done
 timeout -k 10 200 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.log
 for d in pmc_fetch pmc_write pmc_sq calib_fetch calib_write; do python3 tools/pmc_summary.py $OUT/$d > $OUT/$d.txt; done
+python3 tools/pmc_traffic.py $OUT $OUT/hbm_traffic.json
+./tools/valu_rate.bin > $OUT/valu_rate.txt
 echo all done
