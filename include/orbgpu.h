@@ -99,8 +99,9 @@ int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_
                          int32_t feature_count, orbgpu_keypoint *kp, uint8_t *desc, int32_t capacity,
                          int32_t *n_out);
 /* Device-resident form: images, outputs and counts live in HBM.  d_imgs holds n_frames images,
- * frame f at d_imgs + f*frame_stride, rows `stride` bytes apart.  Synchronises the stream before
- * returning only while the quadtree stage runs on the host. */
+ * frame f at d_imgs + f*frame_stride, rows `stride` bytes apart.  Fully asynchronous: every stage, the
+ * quadtree included, is enqueued on the context's stream and the call returns at once; a capacity violation
+ * detected on the device is reported (ORBGPU_E_CAPACITY) by the next orbgpu_synchronize / orbgpu_stage_times. */
 int orbgpu_extract_batch_device(orbgpu_ctx *ctx, const uint8_t *d_imgs, int64_t frame_stride, int32_t stride,
                                 int32_t n_frames, int32_t feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc,
                                 int32_t capacity, int32_t *d_n_out);
