@@ -63,7 +63,7 @@ int build_geometry(orbgpu_ctx *ctx) {
   int budget[ORBGPU_MAX_LEVELS];
   level_budget(p.scale_factor, p.levels, p.max_features, budget);
   unsigned off = 0;
-  int cell_off = 0, cand_off = 0, kp_off = 0, tile_off = 0, ftile_off = 0, xt = 0, yt = 0;
+  int cell_off = 0, cand_off = 0, kp_off = 0, ftile_off = 0, xt = 0, yt = 0;
   for (int l = 0; l < p.levels; l++) {
     LevelGeom &L = g.lv[l];
     const float s = (float)ctx->inv_scale[l];  // :506-508
@@ -92,8 +92,6 @@ int build_geometry(orbgpu_ctx *ctx) {
     L.kp_off = kp_off;
     L.kp_cap = std::max(budget[l], 0) + 4 * ctx->nini[l] + 4;  // the node list overshoots the budget by < 3
     kp_off += L.kp_cap;
-    L.tile_off = tile_off;
-    tile_off += ((L.w + 127) / 128) * ((L.h + 15) / 16);
     L.ftile_off = ftile_off;
     ftile_off += ((L.w + 127) / 128) * ((L.h + 31) / 32);
     L.xtab_off = xt;
@@ -107,7 +105,6 @@ int build_geometry(orbgpu_ctx *ctx) {
   g.cells_per_frame = cell_off;
   g.cands_per_frame = cand_off;
   g.kps_per_frame = kp_off;
-  g.tiles_per_frame = tile_off;
   g.ftiles_per_frame = ftile_off;
   return 0;
 }
@@ -404,16 +401,12 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(dmalloc(&ctx->d_error_flag, 1));
     HIP_TRY(hmalloc(&ctx->h_error_flag, 1));
     *ctx->h_error_flag = 0;
-    HIP_TRY(dmalloc(&ctx->d_cand_count, B * g.levels));
-    HIP_TRY(dmalloc(&ctx->d_cand_prefix, B * g.levels + 1));
     HIP_TRY(dmalloc(&ctx->d_kp_xy, B * g.kps_per_frame));
     HIP_TRY(dmalloc(&ctx->d_kp_count, B * g.levels));
     ctx->out_capacity = g.kps_per_frame;
     HIP_TRY(dmalloc(&ctx->d_out_kp, B * ctx->out_capacity));
     HIP_TRY(dmalloc(&ctx->d_out_desc, B * ctx->out_capacity * 32));
     HIP_TRY(dmalloc(&ctx->d_out_n, B));
-    HIP_TRY(hmalloc(&ctx->h_cand_count, B * g.levels));
-    HIP_TRY(hmalloc(&ctx->h_cand_prefix, B * g.levels + 1));
     HIP_TRY(hmalloc(&ctx->h_cells, B * g.cells_per_frame));
     HIP_TRY(hmalloc(&ctx->h_kp_xy, B * g.kps_per_frame));
     HIP_TRY(hmalloc(&ctx->h_kp_count, B * g.levels));
@@ -433,12 +426,12 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
-                   ctx->d_cands_packed, ctx->d_cand_count, ctx->d_cand_prefix, ctx->d_kp_xy, ctx->d_kp_count,
+                   ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix,
                    ctx->d_error_flag};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
-  void *hptrs[] = {ctx->h_cand_count, ctx->h_cand_prefix, ctx->h_cells, ctx->h_cands, ctx->h_kp_xy, ctx->h_kp_count, ctx->h_imgs, ctx->h_error_flag};
+  void *hptrs[] = {ctx->h_cells, ctx->h_cands, ctx->h_kp_xy, ctx->h_kp_count, ctx->h_imgs, ctx->h_error_flag};
   for (void *p : hptrs)
     if (p) (void)hipHostFree(p);
   for (auto &ev : ctx->ev)

@@ -11,14 +11,49 @@
 
 namespace {
 
-// 256 tests x (x0, y0, x1, y1) signed bytes; read as one dword per test
-__constant__ __attribute__((aligned(16))) signed char c_pattern[256 * 4] = {
+// 256 tests x (x0, y0, x1, y1): pattern_, orb_feature_extractor.cpp:681-852, as floats (one 16-byte load per test)
+struct PatternF { float v[256 * 4]; };
+constexpr PatternF make_pattern() {
+  constexpr int raw[256 * 4] = {
 #include "orb_pattern.inc"
-};
-#define c_pattern4 (reinterpret_cast<const unsigned *>(c_pattern))
+  };
+  PatternF p{};
+  for (int i = 0; i < 256 * 4; i++) p.v[i] = (float)raw[i];
+  return p;
+}
+__constant__ __attribute__((aligned(16))) PatternF c_pattern = make_pattern();
 
 // umax_, orb_feature_extractor.cpp:678-679
-__constant__ int c_umax[ORB_HALF_PATCH + 1] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+constexpr int UMAX[ORB_HALF_PATCH + 1] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+// Orientation weights.  The 31 rows of the disc are read as 9 aligned dwords starting at xo = (cx-15) & ~3; with
+// sh = (cx-15) - xo, byte b of dword c of row r is the pixel u = 4c + b - 15 - sh, v = r - 15.  Per (sh, r, c):
+//   .x = bytes (u + 15) inside the disc, 0 outside   -> v_dot4_u32_u8 gives sum (u+15) I
+//   .y = bytes 1 inside the disc, 0 outside           -> v_dot4_u32_u8 gives sum I
+// so m10 = sum (u+15) I - 15 sum I and m01 = sum over rows of v * (row's sum I).
+constexpr int ODW = 9;                   // aligned dwords covering a 31-byte orientation row
+constexpr int OT_STRIDE = 64 * 5;        // entries per shift (31*9 = 279 used; lane + 63k indexing stays inside)
+struct OrientTab { uint2 e[4 * OT_STRIDE]; };
+constexpr OrientTab make_orient_tab() {
+  OrientTab t{};
+  for (int sh = 0; sh < 4; sh++)
+    for (int r = 0; r < ORB_PATCH; r++)
+      for (int c = 0; c < ODW; c++) {
+        const int v = r - ORB_HALF_PATCH;
+        const int um = UMAX[v < 0 ? -v : v];
+        unsigned w = 0, m = 0;
+        for (int b = 0; b < 4; b++) {
+          const int u = 4 * c + b - ORB_HALF_PATCH - sh;
+          if (u >= -um && u <= um) {
+            w |= (unsigned)(u + ORB_HALF_PATCH) << (8 * b);
+            m |= 1u << (8 * b);
+          }
+        }
+        t.e[sh * OT_STRIDE + r * ODW + c] = uint2{w, m};
+      }
+  return t;
+}
+__constant__ __attribute__((aligned(16))) OrientTab c_orient = make_orient_tab();
 
 // cv::fastAtan2 scalar path: float32, no contraction, correctly rounded divide.
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -50,27 +85,24 @@ constexpr int PW = 2 * PR + 1;      // 39 rows
 constexpr int PDW = 11;             // aligned dwords per staged row: 39 bytes + up to 3 bytes of misalignment
 constexpr int PPITCH = PDW * 4;     // 44
 constexpr int KPB = 8;              // keypoints (waves) per workgroup
-constexpr int ODW = 9;              // aligned dwords covering the 31-byte orientation rows
 
-// packed pattern: one dword per test = (x0, y0, x1, y1) as signed bytes
-__device__ __forceinline__ int sbyte(unsigned v, int k) { return (int)(signed char)((v >> (8 * k)) & 255u); }
-
-// blockDim = 512 = 8 waves = 8 keypoint slots; grid.x = ceil(kps_per_frame / 8), grid.y = frame
+// blockDim = 512 = 8 waves = 8 keypoint slots; 1-D grid over (slot group, frame) in XCD order.
+// Everything that depends only on the slot is forced wave-uniform (readfirstlane) so it runs on the scalar ALU.
 __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                          DeviceGeom g, const short2 *__restrict__ kp_xy,
                                                          const int *__restrict__ kp_count,
                                                          orbgpu_keypoint *__restrict__ out_kp,
                                                          uint8_t *__restrict__ out_desc, int capacity,
                                                          int *__restrict__ out_n, int n_frames) {
-  __shared__ unsigned patch[KPB][PW * PDW];
+  __shared__ unsigned patch[KPB][PW * PDW + 16];
   __shared__ float s_angle[KPB];
   __shared__ float s_cs[KPB][2];
   int f, group;
   if (!xcd_item_frame((g.kps_per_frame + KPB - 1) / KPB, n_frames, group, f)) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int slot = group * KPB + wave;
   const int *cnt = kp_count + f * g.levels;
-  // total and per-level prefix (<= 16 levels; every lane computes the same scalars)
+  // total and per-level prefix (<= 16 levels, scalar)
   int total = 0;
   for (int l = 0; l < g.levels; l++) total += cnt[l];
   if (group == 0 && threadIdx.x == 0) out_n[f] = total;
@@ -91,52 +123,47 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
   int sh = 0;
   if (valid) {
     const short2 xy = kp_xy[(size_t)f * g.kps_per_frame + slot];
-    cx = xy.x;
-    cy = xy.y;
+    cx = __builtin_amdgcn_readfirstlane((int)xy.x);
+    cy = __builtin_amdgcn_readfirstlane((int)xy.y);
     const size_t base = (size_t)f * g.frame_bytes + L.off;
-    // ---- issue the blurred-patch loads first (39 rows x 11 aligned dwords), they land during the orientation
+    // ---- issue the blurred-patch loads first (39 rows x 11 aligned dwords; 5 rows = 55 lanes per step), they land
+    //      during the orientation.  LDS index of (row 5k + lane/11, dword lane%11) is simply 55k + lane.
     const int xb = (cx - PR) & ~3;
     sh = (cx - PR) - xb;
-    unsigned pv[7];
+    const int psub = lane / PDW, pc4 = 4 * (lane - psub * PDW);
+    const uint8_t *bsrc = blur + base + (size_t)(cy - PR) * L.pitch + xb;
+    const unsigned poff = (unsigned)(psub * L.pitch + pc4);
+    unsigned pv[8];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-      const int t = lane + 64 * k;
-      const int r = t / PDW, c = t - r * PDW;
+    for (int k = 0; k < 8; k++) {
       pv[k] = 0;
-      if (t < PW * PDW) pv[k] = *reinterpret_cast<const unsigned *>(blur + base + (size_t)(cy - PR + r) * L.pitch + xb + 4 * c);
+      if (lane < 5 * PDW && 5 * k + psub < PW) pv[k] = *reinterpret_cast<const unsigned *>(bsrc + (poff + (unsigned)(5 * k * L.pitch)));
     }
-    // ---- orientation on the unblurred level (IC_Angle): 31 rows x 9 aligned dwords, one dword per lane-task;
-    //      m10 = sum u*I, m01 = sum v*I over the disc |u| <= umax[|v|]
+    // ---- orientation on the unblurred level (IC_Angle): 31 rows x 9 aligned dwords, 7 rows = 63 lanes per step
     const int xo = (cx - ORB_HALF_PATCH) & ~3;
+    const int osh = (cx - ORB_HALF_PATCH) - xo;
+    const int osub = lane / ODW, oc4 = 4 * (lane - osub * ODW);
+    const uint8_t *osrc = pyr + base + (size_t)(cy - ORB_HALF_PATCH) * L.pitch + xo;
+    const unsigned ooff = (unsigned)(osub * L.pitch + oc4);
     unsigned ov[5];
+    uint2 ow[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      const int t = lane + 64 * k;
-      const int r = t / ODW, c = t - r * ODW;
       ov[k] = 0;
-      if (t < ORB_PATCH * ODW)
-        ov[k] = *reinterpret_cast<const unsigned *>(pyr + base + (size_t)(cy - ORB_HALF_PATCH + r) * L.pitch + xo + 4 * c);
+      ow[k] = c_orient.e[osh * OT_STRIDE + 63 * k + min(lane, 62)];
+      if (lane < 63 && 7 * k + osub < ORB_PATCH) ov[k] = *reinterpret_cast<const unsigned *>(osrc + (ooff + (unsigned)(7 * k * L.pitch)));
     }
-    int m10 = 0, m01 = 0;
+    unsigned a10 = 0, si = 0;
+    int m01 = 0;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      const int t = lane + 64 * k;
-      const int r = t / ODW, c = t - r * ODW;
-      if (t < ORB_PATCH * ODW) {
-        const int v = r - ORB_HALF_PATCH;
-        const int um = c_umax[v < 0 ? -v : v];
-        const int u0 = xo + 4 * c - cx;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const int u = u0 + b;
-          const int val = (int)((ov[k] >> (8 * b)) & 255u);
-          if (u >= -um && u <= um) {
-            m10 += u * val;
-            m01 += v * val;
-          }
-        }
-      }
+      // rows beyond the disc and lane 63 read weight 0 / pixel 0
+      const unsigned rs = __builtin_amdgcn_udot4(ov[k], ow[k].y, 0u, false);
+      a10 = __builtin_amdgcn_udot4(ov[k], ow[k].x, a10, false);
+      si += rs;
+      m01 += (7 * k + osub - ORB_HALF_PATCH) * (int)rs;
     }
+    int m10 = (int)a10 - ORB_HALF_PATCH * (int)si;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       m10 += __shfl_xor(m10, off);
@@ -146,10 +173,8 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
     if (lane == 0) s_angle[wave] = angle;
     unsigned *P = patch[wave];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-      const int t = lane + 64 * k;
-      if (t < PW * PDW) P[t] = pv[k];
-    }
+    for (int k = 0; k < 8; k++)
+      if (lane < 5 * PDW) P[55 * k + lane] = pv[k];   // rows 39.. of the last step land in the 16-dword pad
   }
   __syncthreads();
   // ---- cos/sin for the whole workgroup by 8 lanes of wave 0: float(angle_deg) * (double)(pi/180) -> float,
@@ -164,20 +189,18 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
   if (!valid) return;
   const float a = s_cs[wave][0], b = s_cs[wave][1];
   // ---- rotated BRIEF: taps = cvRound(x*b + y*a), cvRound(x*a - y*b), float32 without FMA
-  const uint8_t *P8 = reinterpret_cast<const uint8_t *>(patch[wave]);
-  const int pc = PR + sh;  // byte column of the keypoint inside a staged row
+  const uint8_t *P8 = reinterpret_cast<const uint8_t *>(patch[wave]) + PR * PPITCH + PR + sh;  // the keypoint's byte
+  const float4 *pat = reinterpret_cast<const float4 *>(c_pattern.v);
   unsigned long long bits[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const unsigned pt = c_pattern4[64 * q + lane];
-    const float x0 = (float)sbyte(pt, 0), y0 = (float)sbyte(pt, 1);
-    const float x1 = (float)sbyte(pt, 2), y1 = (float)sbyte(pt, 3);
-    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = P8[(PR + r0) * PPITCH + pc + c0];
-    const int t1 = P8[(PR + r1) * PPITCH + pc + c1];
+    const float4 pt = pat[64 * q + lane];
+    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+    const int t0 = P8[r0 * PPITCH + c0];
+    const int t1 = P8[r1 * PPITCH + c1];
     bits[q] = __ballot(t0 < t1);  // bit k of byte i = test 8i + k: ballot order is the descriptor's byte order
   }
   if (lane == 0) {

@@ -24,8 +24,7 @@ struct LevelGeom {
   int cell_off;                    // first cell of this level in a frame's cell table
   int cand_off, cand_cap;          // candidate sub-pool (u32 entries) inside a frame's candidate slab
   int kp_off, kp_cap;              // keypoint slots of this level inside a frame's keypoint slab
-  int tile_off;                    // first 128x16 tile of this level in the all-level tile index (blur)
-  int ftile_off;                   // first 128x32 tile of this level in the FAST tile index
+  int ftile_off;                   // first 128x32 tile of this level in the all-level tile index (FAST, blur)
   int xtab_off, ytab_off;          // resize coefficient tables (entries)
   int kp_size;                     // int(31 * scale_factors_[l])
   float scale_f;                   // (float)scale_factors_[l]
@@ -38,7 +37,6 @@ struct DeviceGeom {
   int cells_per_frame;
   int cands_per_frame;
   int kps_per_frame;      // sum of kp_cap
-  int tiles_per_frame;
   int ftiles_per_frame;
   LevelGeom lv[ORBGPU_MAX_LEVELS];
 };
@@ -75,8 +73,6 @@ struct orbgpu_ctx {
   YTab *d_ytab = nullptr;
   CellEntry *d_cells = nullptr;   // [frame][cells_per_frame]
   unsigned *d_cands = nullptr;    // [frame][cands_per_frame]
-  int *d_cand_count = nullptr;    // [frame][levels]
-  int *d_cand_prefix = nullptr;   // [frame*levels + 1] exclusive scan of d_cand_count
   unsigned *d_cands_packed = nullptr;  // dense copy for the host quadtree / key buffer A of the device quadtree
   unsigned *d_cands_tmp = nullptr;     // key buffer B of the device quadtree (levels too large for LDS)
   int *d_cell_prefix = nullptr;        // [frame][cells_per_frame]
@@ -94,7 +90,6 @@ struct orbgpu_ctx {
   int out_capacity = 0;
 
   // pinned host staging
-  int *h_cand_count = nullptr, *h_cand_prefix = nullptr;
   CellEntry *h_cells = nullptr;
   unsigned *h_cands = nullptr;
   size_t h_cands_cap = 0;
