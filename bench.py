@@ -79,23 +79,14 @@ def main():
         if rc != 0:
             raise RuntimeError(lib.orbgpu_last_error(fe.handle).decode())
 
-    stage_acc = np.zeros(7)
-    match_ms_acc = [0.0]
-
-    def step(record):
+    def step():
+        # both calls only enqueue work on the context's stream; nothing waits for the GPU inside the timed loop
         check(lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr(), W * H, W, B, NF, d_kp.data_ptr(),
                                               d_desc.data_ptr(), cap, d_n.data_ptr()))
-        if record:
-            st = fe.stage_times()
-            stage_acc[:] += [st[k] for k in ("pyramid", "fast_score", "cells", "quadtree", "blur", "orient_describe", "total")]
-        t0 = time.perf_counter()
         if n_pairs > 0:
             check(lib.orbgpu_match_frames_device(fe.handle, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
                                                  d_to.data_ptr(), d_from.data_ptr(), n_pairs, 100, 50, 0.9, 1,
                                                  d_match.data_ptr(), d_dist.data_ptr(), d_nm.data_ptr()))
-        check(lib.orbgpu_synchronize(fe.handle))
-        if record:
-            match_ms_acc[0] += (time.perf_counter() - t0) * 1e3
 
     def barrier():
         if world > 1:
@@ -103,13 +94,28 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
     barrier()
+    check(lib.orbgpu_synchronize(fe.handle))   # also resets the stage timers: they now cover the timed steps only
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
-    barrier()
+        step()
+    barrier()                                   # torch.cuda.synchronize() waits for every stream of the device
     elapsed = time.perf_counter() - t0
+    # HIP events recorded on the context's stream around every stage of every timed step (mean over the steps)
+    stt = fe.stage_times()
+    st = np.array([stt[k] for k in ("pyramid", "fast_score", "cells", "quadtree", "blur", "orient_describe", "total")])
+    # the link matcher alone, outside the timed region (informational)
+    link_ms = 0.0
+    if n_pairs > 0:
+        for it in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            check(lib.orbgpu_match_frames_device(fe.handle, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                                                 d_to.data_ptr(), d_from.data_ptr(), n_pairs, 100, 50, 0.9, 1,
+                                                 d_match.data_ptr(), d_dist.data_ptr(), d_nm.data_ptr()))
+            check(lib.orbgpu_synchronize(fe.handle))
+            link_ms = (time.perf_counter() - t1) * 1e3 if it == 0 else min(link_ms, (time.perf_counter() - t1) * 1e3)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -158,7 +164,6 @@ def main():
 
     n_kp = d_n.cpu().numpy()
     n_matches = d_nm.cpu().numpy()[:n_pairs]
-    st = stage_acc / max(args.steps, 1)
     # ---- roofline of the dominant extraction kernel (FAST score map, one launch per batch) --------------
     # algorithmic bytes per launch = P bytes read per frame (SURVEY 8d "FAST (P read)") x frames per launch
     fast_s = st[1] * 1e-3
@@ -184,7 +189,7 @@ def main():
                 "achieved_GBps": round(A * B / ext_s / 1e9, 2) if ext_s > 0 else 0.0,
                 "frac_of_8TBps": round(A * B / ext_s / 1e9 / hbm_peak, 5) if ext_s > 0 else 0.0,
                 "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast_score", "cells", "quadtree", "blur", "orient_describe"), st[:6])},
-                "link_match_ms_per_batch": round(match_ms_acc[0] / max(args.steps, 1), 3)}
+                "link_match_ms_per_batch": round(link_ms, 3)}
 
     matching = {}
     if not args.no_bruteforce:

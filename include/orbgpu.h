@@ -198,9 +198,10 @@ int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to,
                            int32_t n_from, int32_t *match, int32_t *n_discarded);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
-/* Per-stage GPU time of the last extract call in milliseconds (HIP events on the context's stream):
- * [0] pyramid [1] fast score [2] cell NMS + compaction [3] quadtree (host wall time or device)
- * [4] blur [5] orientation + descriptor [6] total.  Used by bench.py for the roofline line. */
+/* Per-stage GPU time in milliseconds (HIP events on the context's stream), averaged over the extract calls
+ * enqueued since the last orbgpu_synchronize / orbgpu_stage_times (at most the last 32); waits for the stream.
+ * [0] pyramid [1] fast score [2] cell NMS + compaction [3] quadtree [4] blur [5] orientation + descriptor
+ * [6] total.  Used by bench.py for the roofline line. */
 int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms7);
 /* Runs a register-resident XOR + v_bcnt_u32_b32 loop and returns descriptor pairs per second: the
  * measured popcount ceiling that BASELINE.md asks to report next to the nominal one. */

@@ -267,14 +267,15 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   int budget[ORBGPU_MAX_LEVELS];
   level_budget(ctx->params.scale_factor, L, feature_count, budget);
   ctx->quadtree_host_ms = 0.f;
-  HIP_TRY(hipMemsetAsync(ctx->d_error_flag, 0, sizeof(int), ctx->stream));
-  HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  // the device error flag is sticky: it is only cleared by finish_pipeline(), so queued calls cannot hide an error
+  hipEvent_t *ev = ctx->ev[ctx->ev_head];
+  HIP_TRY(hipEventRecord(ev[0], ctx->stream));
   for (int l = 1; l < L; l++) launch_pyramid_level(ctx, n_frames, l);
-  HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+  HIP_TRY(hipEventRecord(ev[1], ctx->stream));
   launch_fast_score(ctx, n_frames);
-  HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+  HIP_TRY(hipEventRecord(ev[2], ctx->stream));
   launch_cell_detect(ctx, n_frames);
-  HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+  HIP_TRY(hipEventRecord(ev[3], ctx->stream));
   if (ctx->host_quadtree) {
     int rc = host_quadtree_stage(ctx, n_frames, budget);
     if (rc) return rc;
@@ -282,14 +283,15 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     if (launch_quadtree(ctx, n_frames, budget) != 0)
       return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
   }
-  HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+  HIP_TRY(hipEventRecord(ev[4], ctx->stream));
   launch_blur(ctx, n_frames);
-  HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
+  HIP_TRY(hipEventRecord(ev[5], ctx->stream));
   launch_orient_describe(ctx, n_frames, d_kp, d_desc, capacity, d_n_out);
-  HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
+  HIP_TRY(hipEventRecord(ev[6], ctx->stream));
   HIP_TRY(hipMemcpyAsync(ctx->h_error_flag, ctx->d_error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipGetLastError());
-  ctx->timing_pending = true;
+  ctx->ev_head = (ctx->ev_head + 1) % ORBGPU_EV_SETS;
+  ctx->ev_pending = std::min(ctx->ev_pending + 1, ORBGPU_EV_SETS);
   ctx->last_frames = n_frames;
   ctx->last_feature_count = feature_count;
   return 0;
@@ -298,18 +300,23 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
 // waits for the stream, turns the device error flag into a status and reads the stage timers
 int finish_pipeline(orbgpu_ctx *ctx) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (ctx->timing_pending) {
-    ctx->timing_pending = false;
-    ctx->stage_ms[0] = elapsed(ctx->ev[0], ctx->ev[1]);
-    ctx->stage_ms[1] = elapsed(ctx->ev[1], ctx->ev[2]);
-    ctx->stage_ms[2] = elapsed(ctx->ev[2], ctx->ev[3]);
-    ctx->stage_ms[3] = ctx->host_quadtree ? ctx->quadtree_host_ms : elapsed(ctx->ev[3], ctx->ev[4]);
-    ctx->stage_ms[4] = elapsed(ctx->ev[4], ctx->ev[5]);
-    ctx->stage_ms[5] = elapsed(ctx->ev[5], ctx->ev[6]);
-    ctx->stage_ms[6] = elapsed(ctx->ev[0], ctx->ev[6]);
+  if (ctx->ev_pending > 0) {
+    // stage times: mean over the extract calls enqueued since the last synchronisation (at most ORBGPU_EV_SETS)
+    const int n = ctx->ev_pending;
+    ctx->ev_pending = 0;
+    float acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int k = 1; k <= n; k++) {
+      hipEvent_t *ev = ctx->ev[(ctx->ev_head - k + ORBGPU_EV_SETS) % ORBGPU_EV_SETS];
+      for (int i = 0; i < 6; i++) acc[i] += elapsed(ev[i], ev[i + 1]);
+      acc[6] += elapsed(ev[0], ev[6]);
+    }
+    for (int i = 0; i < 7; i++) ctx->stage_ms[i] = acc[i] / (float)n;
+    if (ctx->host_quadtree) ctx->stage_ms[3] = ctx->quadtree_host_ms;
     if (*ctx->h_error_flag != 0) {
       const int code = *ctx->h_error_flag;
       *ctx->h_error_flag = 0;
+      HIP_TRY(hipMemsetAsync(ctx->d_error_flag, 0, sizeof(int), ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
       return fail(ctx, ORBGPU_E_CAPACITY, "quadtree kernel capacity violation (code " + std::to_string(code) + ")");
     }
   }
@@ -382,7 +389,8 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   auto alloc_all = [&]() -> int {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    for (auto &ev : ctx->ev) HIP_TRY(hipEventCreate(&ev));
+    for (auto &set : ctx->ev)
+      for (auto &ev : set) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(dmalloc(&ctx->d_pyr, B * g.frame_bytes + 256));
     HIP_TRY(dmalloc(&ctx->d_score, B * g.frame_bytes + 256));
     HIP_TRY(dmalloc(&ctx->d_blur, B * g.frame_bytes + 256));
@@ -399,6 +407,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(dmalloc(&ctx->d_cands_tmp, B * g.cands_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cell_prefix, B * g.cells_per_frame));
     HIP_TRY(dmalloc(&ctx->d_error_flag, 1));
+    HIP_TRY(hipMemset(ctx->d_error_flag, 0, sizeof(int)));
     HIP_TRY(hmalloc(&ctx->h_error_flag, 1));
     *ctx->h_error_flag = 0;
     HIP_TRY(dmalloc(&ctx->d_kp_xy, B * g.kps_per_frame));
@@ -434,8 +443,9 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   void *hptrs[] = {ctx->h_cells, ctx->h_cands, ctx->h_kp_xy, ctx->h_kp_count, ctx->h_imgs, ctx->h_error_flag};
   for (void *p : hptrs)
     if (p) (void)hipHostFree(p);
-  for (auto &ev : ctx->ev)
-    if (ev) (void)hipEventDestroy(ev);
+  for (auto &set : ctx->ev)
+    for (auto &ev : set)
+      if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -182,8 +182,10 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
   if (threadIdx.x < KPB) {
     const double factorPI = 3.14159265358979323846 / 180.;
     const float ang = (float)((double)s_angle[threadIdx.x] * factorPI);
-    s_cs[threadIdx.x][0] = (float)cos((double)ang);
-    s_cs[threadIdx.x][1] = (float)sin((double)ang);
+    double sn, cs;
+    sincos((double)ang, &sn, &cs);  // one shared range reduction; same kernels as sin() / cos()
+    s_cs[threadIdx.x][0] = (float)cs;
+    s_cs[threadIdx.x][1] = (float)sn;
   }
   __syncthreads();
   if (!valid) return;

@@ -10,6 +10,7 @@
 
 #include "../../include/orbgpu.h"
 
+#define ORBGPU_EV_SETS 32
 #define ORB_EDGE 19        // EDGE_THRESHOLD, src/features/orb_feature_extractor.h:20
 #define ORB_HALF_PATCH 15  // :18
 #define ORB_PATCH 31       // :19
@@ -79,7 +80,6 @@ struct orbgpu_ctx {
   int *d_error_flag = nullptr;         // set by kernels on capacity violations
   int *h_error_flag = nullptr;
   bool host_quadtree = false;          // ORBGPU_HOST_QUADTREE=1: cross-check path (quadtree.cpp)
-  bool timing_pending = false;
   float quadtree_host_ms = 0.f;
   short2 *d_kp_xy = nullptr;      // [frame][kps_per_frame] level coordinates after the quadtree
   int *d_kp_count = nullptr;      // [frame][levels]
@@ -101,7 +101,8 @@ struct orbgpu_ctx {
   void *d_match_scratch = nullptr;
   size_t match_scratch_bytes = 0;
 
-  hipEvent_t ev[8]{};
+  hipEvent_t ev[ORBGPU_EV_SETS][7]{};  // stage boundaries of the last ORBGPU_EV_SETS extract calls (ring)
+  int ev_head = 0, ev_pending = 0;
   float stage_ms[7]{};
   int last_frames = 0;
   int last_feature_count = 0;
