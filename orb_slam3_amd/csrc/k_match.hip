@@ -377,6 +377,109 @@ __global__ __launch_bounds__(256) void k_link_resolve(const orbgpu_keypoint *__r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused frame-to-frame linking: one workgroup per pair.  AreaToIterator / AreaToPointee only ever pair 'to' id 0 or
+// level-0 'to' ids with level-0 'from' ids (area_to_iterator.h:24-43, area_to_pointee.h:44-48), so the two index
+// lists are compacted first (ascending, which keeps the reference's scan order) and only |to0| x |from0| pairs are
+// evaluated -- about 1/20 of N_to x N_from at 8 levels.  Lists, claims and per-'to' results live in LDS.
+template <class Pred>
+__device__ __forceinline__ int block_compact_list(int n, int *list, int *s_wtot, Pred pred) {
+  // ascending list of i in [0, n) with pred(i); every thread of the 256-thread block calls it; returns the count
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const bool f = i < n && pred(i);
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) s_wtot[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; w++) off += s_wtot[w];
+    if (f) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+    base += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+    __syncthreads();
+  }
+  return base;
+}
+
+__global__ __launch_bounds__(256) void k_link_fused(const orbgpu_keypoint *__restrict__ kp, const uint8_t *__restrict__ desc,
+                                                    const int *__restrict__ n_kp, int capacity,
+                                                    const int *__restrict__ to_frame, const int *__restrict__ from_frame,
+                                                    double window, unsigned threshold, double ratio,
+                                                    int check_orientation, int *__restrict__ match,
+                                                    unsigned *__restrict__ dist, int *__restrict__ n_matches) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lk_lds[];
+  unsigned long long *claim = reinterpret_cast<unsigned long long *>(lk_lds);  // [capacity] per compacted 'from'
+  int *to_list = reinterpret_cast<int *>(claim + capacity);
+  int *from_list = to_list + capacity;
+  int *mj = from_list + capacity;                             // per compacted 'to': compacted 'from' or -1
+  unsigned *md = reinterpret_cast<unsigned *>(mj + capacity);
+  __shared__ int s_wtot[4];
+  __shared__ int total;
+  const int p = blockIdx.x;
+  const int ft = to_frame[p], ff = from_frame[p];
+  const int n_to = min(n_kp[ft], capacity), n_from = min(n_kp[ff], capacity);
+  const orbgpu_keypoint *kt = kp + (size_t)ft * capacity, *kf = kp + (size_t)ff * capacity;
+  int *m = match + (size_t)p * capacity;
+  unsigned *dd = dist + (size_t)p * capacity;
+  for (int i = threadIdx.x; i < capacity; i += 256) {
+    m[i] = -1;
+    dd[i] = 0;
+    claim[i] = ~0ull;
+  }
+  if (threadIdx.x == 0) total = 0;
+  // AreaToIterator visits id 0 whatever its level, later ids only when level == 0
+  const int n_to0 = block_compact_list(n_to, to_list, s_wtot, [&](int i) { return i == 0 || kt[i].level == 0; });
+  const int n_from0 = block_compact_list(n_from, from_list, s_wtot, [&](int j) { return kf[j].level == 0; });
+  const uint4 *__restrict__ fdesc = reinterpret_cast<const uint4 *>(desc + (size_t)ff * capacity * 32);
+  for (int s0 = 0; s0 < n_to0; s0 += 256) {
+    const int slot = s0 + threadIdx.x;
+    const int ti = to_list[min(slot, n_to0 - 1)];
+    const orbgpu_keypoint k = kt[ti];
+    const uint4 *td = reinterpret_cast<const uint4 *>(desc + ((size_t)ft * capacity + ti) * 32);
+    const uint4 t0 = td[0], t1 = td[1];
+    const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    unsigned best = KEY_NONE, second = KEY_NONE;
+    for (int c = 0; c < n_from0; c++) {
+      const int j = __builtin_amdgcn_readfirstlane(from_list[c]);  // wave-uniform: the loads below are scalar
+      const uint4 a = fdesc[2 * j], b = fdesc[2 * j + 1];
+      const double fx = kf[j].x, fy = kf[j].y;
+      unsigned key = (hamming8(t, a, b) << IDX_BITS) | (unsigned)c;
+      // ListFeaturesInArea(point, window, 0, 0): strict |dx| < r and |dy| < r in double (features.cpp:109-119)
+      const bool ok = fabs(fx - k.x) < window && fabs(fy - k.y) < window;
+      key = ok ? key : KEY_NONE;
+      second = umed3(best, key, second);
+      best = min(best, key);
+    }
+    if (slot < n_to0) {
+      unsigned d = 0;
+      const int cm = snn_accept(best, second, threshold, ratio, d);
+      mj[slot] = cm;
+      md[slot] = d;
+      dd[ti] = d;
+      if (cm >= 0) atomicMin(&claim[cm], ((unsigned long long)d << 32) | (unsigned)ti);
+    }
+  }
+  __syncthreads();
+  int cnt = 0;
+  for (int slot = threadIdx.x; slot < n_to0; slot += 256) {
+    const int cm = mj[slot];
+    const int ti = to_list[slot];
+    if (cm >= 0 && claim[cm] == (((unsigned long long)md[slot] << 32) | (unsigned)ti)) {
+      m[ti] = from_list[cm];
+      cnt++;
+    }
+  }
+  if (cnt) atomicAdd(&total, cnt);
+  __syncthreads();  // also orders this block's global writes to m[] before the filter reads them
+  if (!check_orientation) {
+    if (threadIdx.x == 0) n_matches[p] = total;
+    return;
+  }
+  rotation_filter_block(
+      n_to, m, [&](int i) { return kt[i].angle; }, [&](int j) { return kf[j].angle; }, nullptr, &n_matches[p]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // All-pairs keyframe matching: 'to' = keyframe r of the row set, 'from' = keyframe c of the column set,
 // SNNMatcher::MatchWithIterators semantics with no candidate restriction (every 'from' in index order), then the
 // optional rotation histogram.  One workgroup owns one (r, c) pair from the scan to the match count, so nothing but
@@ -560,10 +663,19 @@ void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a, int *d_from_
                      claim);
 }
 
+size_t link_fused_lds_bytes(int capacity) { return (size_t)capacity * 24; }
+
 void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const uint8_t *d_desc, const int *d_n,
                          int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
                          unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,
                          int *d_n_matches) {
+  if (link_fused_lds_bytes(capacity) <= 64 * 1024) {
+    hipLaunchKernelGGL(k_link_fused, dim3(n_pairs), dim3(256), link_fused_lds_bytes(capacity), c->stream, d_kp, d_desc, d_n,
+                       capacity, d_to_frame, d_from_frame, (double)window, std::min(threshold, 256u), ratio,
+                       check_orientation, d_match, d_dist, d_n_matches);
+    return;
+  }
+  // very large keypoint capacities: three-kernel path through global scratch
   // scratch: claim [pairs][capacity] u64, partial [pairs][chunks][capacity] uint2
   const int chunk = 256;
   const int n_chunks = (capacity + chunk - 1) / chunk;

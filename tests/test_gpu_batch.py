@@ -8,12 +8,14 @@ from orb_slam3_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def test_batch_device_extract_and_link(oracle):
+@pytest.mark.parametrize("W,H,NF,B", [(320, 240, 400, 6), (640, 480, 3000, 3)])
+def test_batch_device_extract_and_link(oracle, W, H, NF, B):
+    """The second case has a keypoint capacity above what the fused per-pair link kernel keeps in LDS, so it takes
+    the three-kernel path through global scratch."""
     import torch
     from orb_slam3_amd import _lib
     from orb_slam3_amd.features import ORBFeatureExtractor
     lib = _lib.load()
-    W, H, NF, B = 320, 240, 400, 6
     frames = synth.sequence(77, B, H, W)
     fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_batch=B, max_features=NF)
     cap = fe.geometry(NF).keypoint_capacity
@@ -25,9 +27,9 @@ def test_batch_device_extract_and_link(oracle):
     rc = lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr(), W * H, W, B, NF, d_kp.data_ptr(),
                                          d_desc.data_ptr(), cap, d_n.data_ptr())
     assert rc == 0, lib.orbgpu_last_error(fe.handle)
-    to = torch.tensor([1, 2, 3, 4, 5, 0], dtype=torch.int32, device=dev)
-    frm = torch.tensor([0, 1, 2, 3, 4, 5], dtype=torch.int32, device=dev)
-    npairs = 6
+    to = torch.tensor([(i + 1) % B for i in range(B)], dtype=torch.int32, device=dev)
+    frm = torch.tensor(list(range(B)), dtype=torch.int32, device=dev)
+    npairs = B
     d_m = torch.zeros((npairs, cap), dtype=torch.int32, device=dev)
     d_d = torch.zeros((npairs, cap), dtype=torch.int32, device=dev)
     d_nm = torch.zeros(npairs, dtype=torch.int32, device=dev)
