@@ -63,7 +63,7 @@ int build_geometry(orbgpu_ctx *ctx) {
   int budget[ORBGPU_MAX_LEVELS];
   level_budget(p.scale_factor, p.levels, p.max_features, budget);
   unsigned off = 0;
-  int cell_off = 0, cand_off = 0, kp_off = 0, ftile_off = 0, xt = 0, yt = 0;
+  int cell_off = 0, cand_off = 0, kp_off = 0, ftile_off = 0, xt = 0, yt = 0, mask_off = 0;
   for (int l = 0; l < p.levels; l++) {
     LevelGeom &L = g.lv[l];
     const float s = (float)ctx->inv_scale[l];  // :506-508
@@ -93,6 +93,9 @@ int build_geometry(orbgpu_ctx *ctx) {
     L.kp_cap = std::max(budget[l], 0) + 4 * ctx->nini[l] + 4;  // the node list overshoots the budget by < 3
     kp_off += L.kp_cap;
     L.ftile_off = ftile_off;
+    L.mask_pitch = ((L.w + 127) / 128) * 4;  // whole 128-pixel tiles: the FAST kernel writes 4 dwords per tile row
+    L.mask_off = mask_off;
+    mask_off += L.mask_pitch * L.h;
     ftile_off += ((L.w + 127) / 128) * ((L.h + 31) / 32);
     L.xtab_off = xt;
     L.ytab_off = yt;
@@ -106,6 +109,7 @@ int build_geometry(orbgpu_ctx *ctx) {
   g.cands_per_frame = cand_off;
   g.kps_per_frame = kp_off;
   g.ftiles_per_frame = ftile_off;
+  g.mask_dwords_per_frame = mask_off;
   return 0;
 }
 
@@ -394,6 +398,8 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(dmalloc(&ctx->d_pyr, B * g.frame_bytes + 256));
     HIP_TRY(dmalloc(&ctx->d_score, B * g.frame_bytes + 256));
     HIP_TRY(dmalloc(&ctx->d_blur, B * g.frame_bytes + 256));
+    HIP_TRY(dmalloc(&ctx->d_nzmask, B * (size_t)g.mask_dwords_per_frame + 64));
+    HIP_TRY(hipMemsetAsync(ctx->d_nzmask, 0, (B * (size_t)g.mask_dwords_per_frame + 64) * sizeof(unsigned), ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_pyr, 0, B * g.frame_bytes + 256, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_score, 0, B * g.frame_bytes + 256, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_blur, 0, B * g.frame_bytes + 256, ctx->stream));
@@ -434,7 +440,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
+  void *dptrs[] = {ctx->d_nzmask, ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix,
                    ctx->d_error_flag};

@@ -95,10 +95,11 @@ constexpr int FT_H = 32;                 // FAST tile: 128 x 32 pixels, 256 thre
 constexpr int FT_ROWS = FT_H + 6;
 
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score,
-                                                    DeviceGeom g, int n_frames) {
+                                                    unsigned *__restrict__ nzmask, DeviceGeom g, int n_frames) {
   __shared__ unsigned tile[FT_ROWS * TILE_DW];
   __shared__ unsigned out_tile[FT_H * TILE_W / 4];
   __shared__ unsigned short queue[FT_H * TILE_W];
+  __shared__ unsigned rowmask[FT_H * 4];  // bit (cx & 31) of rowmask[ry*4 + cx/32]: score(cx, ry) != 0
   __shared__ int q_count;
   int t, frame, l = 0;
   if (!xcd_item_frame(g.ftiles_per_frame, n_frames, t, frame)) return;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
   const uint8_t *src = pyr + base;
 
   if (threadIdx.x == 0) q_count = 0;
+  if (threadIdx.x < FT_H * 4) rowmask[threadIdx.x] = 0;
 #pragma unroll
   for (int k = 0; k < FT_H * TILE_W / 4 / 256; k++) out_tile[threadIdx.x + 256 * k] = 0;
   // 38 x 34 dwords; pixels outside the image are never part of a scored ring
@@ -214,7 +216,9 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     r[4] = c[3];            r[5] = c[-RP + 3];      r[6] = c[-2 * RP + 2];  r[7] = c[-3 * RP + 1];
     r[8] = c[-3 * RP];      r[9] = c[-3 * RP - 1];  r[10] = c[-2 * RP - 2]; r[11] = c[-RP - 3];
     r[12] = c[-3];          r[13] = c[RP - 3];      r[14] = c[2 * RP - 2];  r[15] = c[3 * RP - 1];
-    ob[idx] = (uint8_t)fast_score16_full((int)c[0], r, min_thr);
+    const int sc = fast_score16_full((int)c[0], r, min_thr);
+    ob[idx] = (uint8_t)sc;
+    if (sc) atomicOr(&rowmask[ry * 4 + (cx >> 5)], 1u << (cx & 31));
   }
   __syncthreads();
   // ---- phase 3: coalesced write-back ---------------------------------------------------------------
@@ -225,6 +229,10 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     if (y >= L.h || x >= L.pitch) continue;
     *reinterpret_cast<unsigned *>(score + base + (size_t)y * L.pitch + x) = out_tile[ry * (TILE_W / 4) + tx];
   }
+  // the non-zero bit plane: 4 dwords per tile row (k_cell_detect finds its queue entries from it)
+  if (threadIdx.x < FT_H * 4 && y0 + (int)(threadIdx.x >> 2) < L.h)
+    nzmask[(size_t)frame * g.mask_dwords_per_frame + L.mask_off + (size_t)(y0 + (threadIdx.x >> 2)) * L.mask_pitch + (x0 >> 5) +
+           (threadIdx.x & 3)] = rowmask[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -240,27 +248,33 @@ constexpr int CELL_DW = 16;
 constexpr int CELL_PITCH = CELL_DW * 4;
 constexpr int CQ_CAP = 512;        // queue entries; denser cells take the division-based dense path
 constexpr int CELLS_PER_WG = 4;
+__host__ __device__ constexpr size_t cell_lds_bytes(int cell_rows) { return (size_t)cell_rows * (CELL_PITCH + 16) + CQ_CAP * 2; }
 
-__global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t *__restrict__ score, DeviceGeom g,
+__global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t *__restrict__ score,
+                                                                   const unsigned *__restrict__ nzmask, DeviceGeom g,
                                                                    CellEntry *__restrict__ cells,
-                                                                   unsigned *__restrict__ cands, int n_frames) {
-  __shared__ unsigned s32_all[CELLS_PER_WG][CELL_MAX * CELL_DW];
-  __shared__ unsigned short queue_all[CELLS_PER_WG][CQ_CAP];
-  __shared__ unsigned long long m_hi_all[CELLS_PER_WG][CELL_MAX], m_lo_all[CELLS_PER_WG][CELL_MAX];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  unsigned *s32 = s32_all[wave];
+                                                                   unsigned *__restrict__ cands, int n_frames,
+                                                                   int cell_rows) {
+  // dynamic LDS, per wave: score rectangle [cell_rows][16 dwords] | NMS ballots hi, lo [cell_rows] | queue [CQ_CAP]
+  extern __shared__ __attribute__((aligned(16))) unsigned char cd_lds[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  unsigned char *wbase = cd_lds + (size_t)wave * cell_lds_bytes(cell_rows);
+  unsigned *s32 = reinterpret_cast<unsigned *>(wbase);
   const uint8_t *s8 = reinterpret_cast<const uint8_t *>(s32);
-  unsigned short *queue = queue_all[wave];
-  unsigned long long *m_hi = m_hi_all[wave], *m_lo = m_lo_all[wave];
+  unsigned long long *m_hi = reinterpret_cast<unsigned long long *>(wbase + (size_t)cell_rows * CELL_PITCH);
+  unsigned long long *m_lo = m_hi + cell_rows;
+  unsigned short *queue = reinterpret_cast<unsigned short *>(m_lo + cell_rows);
   int f, c, l = 0;
   if (!xcd_item_frame((g.cells_per_frame + CELLS_PER_WG - 1) / CELLS_PER_WG, n_frames, c, f)) return;
-  c = c * CELLS_PER_WG + wave;
+  c = c * CELLS_PER_WG + wave;  // wave-uniform: the cell geometry below runs on the scalar ALU
   if (c >= g.cells_per_frame) return;
 #pragma unroll 1
   while (l + 1 < g.levels && c >= g.lv[l + 1].cell_off) l++;
   const LevelGeom L = g.lv[l];
   const int ci = c - L.cell_off;
-  const int i = ci / L.ncols, j = ci - i * L.ncols;
+  int i = (int)(((float)ci + 0.5f) * (1.0f / (float)L.ncols));  // ci / ncols, exact for ci < 2^20
+  i = __builtin_amdgcn_readfirstlane(i);
+  const int j = ci - i * L.ncols;
   const int x0 = ORB_EDGE + j * L.wcell, x1 = min(ORB_EDGE - 1 + (j + 1) * L.wcell, L.w - ORB_EDGE - 1);
   const int y0 = ORB_EDGE + i * L.hcell, y1 = min(ORB_EDGE - 1 + (i + 1) * L.hcell, L.h - ORB_EDGE - 1);
   const int rw = x1 - x0 + 1, rh = y1 - y0 + 1;
@@ -281,38 +295,48 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
   for (int b = 0; b < 4; b++)
     if (4 * dd + b >= cxa && 4 * dd + b < cxa + rw) bmask |= 0xffu << (8 * b);
 
-  // ---- stage + compact the non-zero pixels (raster order: 4 rows per step, lane = row*16 + dword, then byte) ----
-  int nq = 0;
-  unsigned w[16];  // all row steps in flight at once: rh <= 64 = 16 steps of 4 rows
+  // ---- stage the rectangle (4 rows per step, all loads in flight) ------------------------------------------
+  unsigned w[16];  // rh <= 64 = 16 steps of 4 rows
 #pragma unroll
   for (int u = 0; u < 16; u++) {
     const int r = 4 * u + rsub;
     w[u] = 0;
-    if (r < rh && dd < ndwr) w[u] = *reinterpret_cast<const unsigned *>(src + (size_t)(y0 + r) * L.pitch + xa + 4 * dd) & bmask;
+    if (4 * u < rh)  // uniform
+      if (r < rh && dd < ndwr) w[u] = *reinterpret_cast<const unsigned *>(src + (size_t)(y0 + r) * L.pitch + xa + 4 * dd) & bmask;
   }
+  // ---- queue of the non-zero pixels in raster order, from the bit plane k_fast_score wrote: lane = row ---------
+  unsigned long long rowbits = 0;
+  if (lane < rh) {
+    const unsigned *mrow = nzmask + (size_t)f * g.mask_dwords_per_frame + L.mask_off + (size_t)(y0 + lane) * L.mask_pitch;
+    const int d0 = x0 >> 5, sft = x0 & 31;
+    const unsigned m0 = mrow[d0];
+    const unsigned m1 = d0 + 1 < L.mask_pitch ? mrow[d0 + 1] : 0u;
+    const unsigned m2 = d0 + 2 < L.mask_pitch ? mrow[d0 + 2] : 0u;
+    const unsigned long long lo = ((unsigned long long)m1 << 32) | m0;
+    rowbits = sft ? (lo >> sft) | ((unsigned long long)m2 << (64 - sft)) : lo;
+    rowbits &= (rw >= 64) ? ~0ull : ((1ull << rw) - 1ull);
+  }
+  const int cnt = __popcll(rowbits);
+  int incl = cnt;  // inclusive scan over the rows (lanes)
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  const int nq = __shfl(incl, 63);
 #pragma unroll
   for (int u = 0; u < 16; u++) {
     const int r = 4 * u + rsub;
-    if (4 * u < rh) {
+    if (4 * u < rh)
       if (r < rh) s32[r * CELL_DW + dd] = w[u];
-      const unsigned long long any = __ballot(w[u] != 0);
-      if (any != 0) {
-        unsigned long long bb[4];
-        int tot = 0, mine = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          bb[b] = __ballot(((w[u] >> (8 * b)) & 255u) != 0);
-          tot += __popcll(bb[b]);
-          mine += __popcll(bb[b] & below);
-        }
-        if (nq + tot <= CQ_CAP) {
-          int pos = nq + mine;
-#pragma unroll
-          for (int b = 0; b < 4; b++)
-            if ((w[u] >> (8 * b)) & 255u) queue[pos++] = (unsigned short)((r << 6) | (4 * dd + b));
-        }
-        nq += tot;
-      }
+  }
+  if (nq <= CQ_CAP) {
+    int pos = incl - cnt;
+    unsigned long long bits = rowbits;
+    while (bits) {
+      const int bpos = __ffsll((long long)bits) - 1;
+      bits &= bits - 1;
+      queue[pos++] = (unsigned short)((lane << 6) | (cxa + bpos));
     }
   }
   __builtin_amdgcn_wave_barrier();  // LDS traffic of one wave is processed in order
@@ -394,11 +418,14 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
 
 void launch_fast_score(const orbgpu_ctx *c, int n_frames) {
   dim3 grid(c->geom.ftiles_per_frame * xcd_frames(n_frames));
-  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_score, c->geom, n_frames);
+  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_score, c->d_nzmask, c->geom, n_frames);
 }
 
 void launch_cell_detect(const orbgpu_ctx *c, int n_frames) {
+  int cell_rows = 1;
+  for (int l = 0; l < c->geom.levels; l++) cell_rows = std::max(cell_rows, c->geom.lv[l].hcell);
+  cell_rows = std::min((cell_rows + 3) & ~3, CELL_MAX);  // hcell <= 64 is checked at create time
   dim3 grid((c->geom.cells_per_frame + CELLS_PER_WG - 1) / CELLS_PER_WG * xcd_frames(n_frames));
-  hipLaunchKernelGGL(k_cell_detect, grid, dim3(64 * CELLS_PER_WG), 0, c->stream, c->d_score, c->geom, c->d_cells, c->d_cands,
-                     n_frames);
+  hipLaunchKernelGGL(k_cell_detect, grid, dim3(64 * CELLS_PER_WG), CELLS_PER_WG * cell_lds_bytes(cell_rows), c->stream,
+                     c->d_score, c->d_nzmask, c->geom, c->d_cells, c->d_cands, n_frames, cell_rows);
 }

@@ -26,6 +26,7 @@ struct LevelGeom {
   int cand_off, cand_cap;          // candidate sub-pool (u32 entries) inside a frame's candidate slab
   int kp_off, kp_cap;              // keypoint slots of this level inside a frame's keypoint slab
   int ftile_off;                   // first 128x32 tile of this level in the all-level tile index (FAST, blur)
+  int mask_off, mask_pitch;        // non-zero-score bit plane: first dword of the level, dwords per row
   int xtab_off, ytab_off;          // resize coefficient tables (entries)
   int kp_size;                     // int(31 * scale_factors_[l])
   float scale_f;                   // (float)scale_factors_[l]
@@ -39,6 +40,7 @@ struct DeviceGeom {
   int cands_per_frame;
   int kps_per_frame;      // sum of kp_cap
   int ftiles_per_frame;
+  int mask_dwords_per_frame;
   LevelGeom lv[ORBGPU_MAX_LEVELS];
 };
 
@@ -70,6 +72,7 @@ struct orbgpu_ctx {
 
   // device slabs, sized for max_batch frames
   uint8_t *d_pyr = nullptr, *d_score = nullptr, *d_blur = nullptr;
+  unsigned *d_nzmask = nullptr;   // [frame][mask_dwords_per_frame]: bit x of row y set iff score(x, y) != 0
   XTab *d_xtab = nullptr;
   YTab *d_ytab = nullptr;
   CellEntry *d_cells = nullptr;   // [frame][cells_per_frame]
