@@ -2,6 +2,7 @@
 // extraction pipeline and the host-pointer wrappers of the matching entry points.  gfx950 only.
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -109,6 +110,11 @@ int build_geometry(orbgpu_ctx *ctx) {
   g.cands_per_frame = cand_off;
   g.kps_per_frame = kp_off;
   g.ftiles_per_frame = ftile_off;
+  for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) {
+    g.kp_offs[l] = l < g.levels ? g.lv[l].kp_off : INT_MAX;
+    g.ftile_offs[l] = l < g.levels ? g.lv[l].ftile_off : INT_MAX;
+    g.cell_offs[l] = l < g.levels ? g.lv[l].cell_off : INT_MAX;
+  }
   g.mask_dwords_per_frame = mask_off;
   return 0;
 }

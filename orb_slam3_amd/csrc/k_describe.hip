@@ -97,26 +97,32 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
   __shared__ unsigned patch[KPB][PW * PDW + 16];
   __shared__ float s_angle[KPB];
   __shared__ float s_cs[KPB][2];
+  __shared__ int s_prefix[ORBGPU_MAX_LEVELS];
   int f, group;
   if (!xcd_item_frame((g.kps_per_frame + KPB - 1) / KPB, n_frames, group, f)) return;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  // the lane's 4 test patterns: independent of everything else, so their latency hides behind the whole kernel
+  const float4 *pat = reinterpret_cast<const float4 *>(c_pattern.v);
+  float4 ptn[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) ptn[q] = pat[64 * q + lane];
   const int slot = group * KPB + wave;
   const int *cnt = kp_count + f * g.levels;
-  // total and per-level prefix (<= 16 levels, scalar)
-  int total = 0;
-  for (int l = 0; l < g.levels; l++) total += cnt[l];
-  if (group == 0 && threadIdx.x == 0) out_n[f] = total;
-  // validity is wave-uniform; invalid waves only take part in the barriers
-  bool valid = slot < g.kps_per_frame && total <= capacity;
-  int l = 0;
-#pragma unroll 1
-  while (l + 1 < g.levels && slot >= g.lv[l + 1].kp_off) l++;
+  const int l = level_of(g.kp_offs, slot);
   const LevelGeom L = g.lv[l];
   const int i = slot - L.kp_off;
-  valid = valid && i < cnt[l];
-  int before = 0;
-  for (int q = 0; q < l; q++) before += cnt[q];
-  const int pos = total - 1 - (before + i);  // reversed packing, SURVEY App. B.4
+  // validity is wave-uniform; invalid waves only take part in the barriers
+  const bool valid = slot < g.kps_per_frame && i < cnt[l];
+  // inclusive prefix of the per-level counts, once per workgroup (16 lanes of wave 0); read after the barriers
+  if (threadIdx.x < ORBGPU_MAX_LEVELS) {
+    int v = (int)threadIdx.x < g.levels ? cnt[threadIdx.x] : 0;
+#pragma unroll
+    for (int o = 1; o < ORBGPU_MAX_LEVELS; o <<= 1) {
+      const int u = __shfl_up(v, o);
+      if ((int)threadIdx.x >= o) v += u;
+    }
+    s_prefix[threadIdx.x] = v;
+  }
 
   int cx = 0, cy = 0;
   float angle = 0.f;
@@ -188,15 +194,17 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
     s_cs[threadIdx.x][1] = (float)sn;
   }
   __syncthreads();
-  if (!valid) return;
+  const int total = s_prefix[ORBGPU_MAX_LEVELS - 1];
+  if (group == 0 && threadIdx.x == 0) out_n[f] = total;
+  if (!valid || total > capacity) return;
+  const int pos = total - 1 - ((l ? s_prefix[l - 1] : 0) + i);  // reversed packing, SURVEY App. B.4
   const float a = s_cs[wave][0], b = s_cs[wave][1];
   // ---- rotated BRIEF: taps = cvRound(x*b + y*a), cvRound(x*a - y*b), float32 without FMA
   const uint8_t *P8 = reinterpret_cast<const uint8_t *>(patch[wave]) + PR * PPITCH + PR + sh;  // the keypoint's byte
-  const float4 *pat = reinterpret_cast<const float4 *>(c_pattern.v);
   unsigned long long bits[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const float4 pt = pat[64 * q + lane];
+    const float4 pt = ptn[q];
     const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
     const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
     const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));

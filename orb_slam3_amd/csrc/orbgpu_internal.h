@@ -41,8 +41,18 @@ struct DeviceGeom {
   int kps_per_frame;      // sum of kp_cap
   int ftiles_per_frame;
   int mask_dwords_per_frame;
+  // compact copies of the per-level offsets (INT_MAX beyond the last level): one wide scalar load finds a level
+  int kp_offs[ORBGPU_MAX_LEVELS], ftile_offs[ORBGPU_MAX_LEVELS], cell_offs[ORBGPU_MAX_LEVELS];
   LevelGeom lv[ORBGPU_MAX_LEVELS];
 };
+
+// level of item `i` given ascending first-item offsets (offs[0] = 0): branch-free, no dependent loads
+__device__ __forceinline__ int level_of(const int (&offs)[ORBGPU_MAX_LEVELS], int i) {
+  int l = 0;
+#pragma unroll
+  for (int q = 1; q < ORBGPU_MAX_LEVELS; q++) l += (i >= offs[q]) ? 1 : 0;
+  return l;
+}
 
 // resize tables: built on the host in the exact float/double sequence
 struct XTab { int sx0, sx1; short a0, a1; };

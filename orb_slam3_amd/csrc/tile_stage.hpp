@@ -16,9 +16,14 @@ inline int xcd_frames(int n_frames) { return (n_frames + 7) & ~7; }
 __device__ __forceinline__ bool xcd_item_frame(int items_per_frame, int n_frames, int &item, int &frame) {
   const unsigned id = blockIdx.x;
   const unsigned j = id >> 3;
-  const unsigned fq = j / (unsigned)items_per_frame;
-  item = (int)(j - fq * (unsigned)items_per_frame);
-  frame = (int)(fq * 8u + (id & 7u));
+  // j / items_per_frame from a float estimate and a two-sided fix-up: the quotient (a frame-group index) is far
+  // below 2^22, so the estimate is off by at most one
+  int fq = (int)((float)j * (1.0f / (float)items_per_frame));
+  int it = (int)j - fq * items_per_frame;
+  if (it < 0) { fq--; it += items_per_frame; }
+  if (it >= items_per_frame) { fq++; it -= items_per_frame; }
+  item = it;
+  frame = fq * 8 + (int)(id & 7u);
   return frame < n_frames;
 }
 
