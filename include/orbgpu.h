@@ -163,6 +163,34 @@ int orbgpu_match_window(orbgpu_ctx *ctx, const orbgpu_window_args *args, int32_t
 int orbgpu_match_window_device(orbgpu_ctx *ctx, const orbgpu_window_args *device_args, int32_t *d_from_idx_per_to,
                                uint32_t *d_dist);
 
+/* replaces: the matcher inside DBoW2Handler::FastMatch (features/handlers/DBoW2/dbo_w2_handler.cpp:25-72):
+ * SNNMatcher<BowToIterator>, candidates restricted to features of the same vocabulary node
+ * (handlers/DBoW2/bow_to_iterator.cpp:12-47, bow_to_pointee.h:37-45).  The caller joins the two
+ * DBoW2::FeatureVector maps (merge join on node id, as AdvanceUntilSameNode does) and passes the shared nodes
+ * in node order: group g = 'to' ids to_ids[to_off[g] .. to_off[g+1]) and 'from' ids
+ * from_ids[from_off[g] .. from_off[g+1]), each in the order of the node's std::vector.  A 'to' id may appear in
+ * one group only (a feature has one node).  Thresholds of the three severities: dbo_w2_handler.cpp:37-51.
+ * Outputs are indexed by 'to' id: from index or -1, and the distance.  The rotation filter is
+ * orbgpu_rotation_filter, as in the reference (:68-71). */
+typedef struct {
+  const uint8_t *to_desc;   /* n_to x 32 */
+  int32_t n_to;
+  const uint8_t *from_desc; /* n_from x 32 */
+  int32_t n_from;
+  int32_t n_groups;
+  const int32_t *to_off;    /* n_groups + 1, to_off[0] = 0 */
+  const uint32_t *to_ids;   /* to_off[n_groups] */
+  const int32_t *from_off;  /* n_groups + 1, from_off[0] = 0 */
+  const uint32_t *from_ids; /* from_off[n_groups] */
+  uint32_t threshold;
+  double ratio;
+} orbgpu_group_args;
+int orbgpu_match_groups(orbgpu_ctx *ctx, const orbgpu_group_args *args, int32_t *from_idx_per_to, uint32_t *dist);
+/* device form: every pointer in *device_args and both outputs are device pointers; n_slots = to_off[n_groups]
+ * (the host knows it from building the join); asynchronous on the context's stream. */
+int orbgpu_match_groups_device(orbgpu_ctx *ctx, const orbgpu_group_args *device_args, int32_t n_slots,
+                               int32_t *d_from_idx_per_to, uint32_t *d_dist);
+
 /* replaces: MonocularFrame::ComputeMatchesForLinking (frame/monocular/monocular_frame.cpp:173-189) for
  * consecutive frames of a device-resident batch produced by orbgpu_extract_batch_device: for pair p,
  * 'to' = frame to_frame[p], 'from' = frame from_frame[p]; AreaToIterator window semantics

@@ -972,6 +972,72 @@ int oo_snn_match(const oo_match_args *a, int32_t *match_from, uint32_t *match_di
   return nmatches;
 }
 
+/* lower_bound over ascending node ids: first k in [lo, n) with nodes[k] >= key (std::map::lower_bound) */
+static int node_lower_bound(const uint32_t *nodes, int lo, int n, uint32_t key) {
+  int k = lo;
+  while (k < n && nodes[k] < key) k++;
+  return k;
+}
+
+int oo_match_bow(const uint8_t *desc_to, int n_to, const uint8_t *desc_from, int n_from, const uint32_t *to_nodes,
+                 const int32_t *to_off, const uint32_t *to_ids, int n_to_nodes, const uint32_t *from_nodes,
+                 const int32_t *from_off, const uint32_t *from_ids, int n_from_nodes, unsigned threshold, double ratio,
+                 int32_t *match_from, uint32_t *match_dist) {
+  uint32_t *best_from_dist = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n_from ? n_from : 1));
+  int32_t *from_to = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_from ? n_from : 1));
+  for (int j = 0; j < n_from; j++) from_to[j] = -1;
+  for (int i = 0; i < n_to; i++) match_from[i] = -1;
+  int nmatches = 0;
+  int kt = 0, kf = 0; /* bow_it_to_, bow_it_from_ */
+  /* BowToIterator::AdvanceUntilSameNode / operator++, bow_to_iterator.cpp:12-47 */
+  while (kt < n_to_nodes && kf < n_from_nodes) {
+    if (to_nodes[kt] != from_nodes[kf]) {
+      if (to_nodes[kt] < from_nodes[kf])
+        kt = node_lower_bound(to_nodes, 0, n_to_nodes, from_nodes[kf]);
+      else
+        kf = node_lower_bound(from_nodes, 0, n_from_nodes, to_nodes[kt]);
+      continue;
+    }
+    /* same node: every 'to' id of the node, candidates = the node's 'from' ids (bow_to_pointee.h:37-45) */
+    for (int s = to_off[kt]; s < to_off[kt + 1]; s++) {
+      const int i = (int)to_ids[s];
+      unsigned best = UINT_MAX, second = UINT_MAX;
+      int best_j = -1;
+      const uint8_t *d1 = desc_to + (size_t)i * 32;
+      for (int c = from_off[kf]; c < from_off[kf + 1]; c++) {
+        const int j = (int)from_ids[c];
+        unsigned distance = oo_hamming256(d1, desc_from + (size_t)j * 32);
+        if (distance > threshold) continue;
+        if (distance < best) {
+          best_j = j;
+          second = best;
+          best = distance;
+        } else if (distance < second)
+          second = distance;
+      }
+      if ((double)best < ratio * (double)second) {
+        if (from_to[best_j] >= 0) {
+          if (best_from_dist[best_j] > best) {
+            match_from[from_to[best_j]] = -1;
+            nmatches--;
+          } else
+            continue;
+        }
+        best_from_dist[best_j] = best;
+        from_to[best_j] = i;
+        match_from[i] = best_j;
+        if (match_dist) match_dist[i] = best;
+        nmatches++;
+      }
+    }
+    kt++; /* operator++ past the node's last id: both map iterators advance, :21-25 */
+    kf++;
+  }
+  free(best_from_dist);
+  free(from_to);
+  return nmatches;
+}
+
 int oo_match_area(const oo_keypoint *kp_to, const uint8_t *desc_to, int n_to, const oo_keypoint *kp_from,
                   const uint8_t *desc_from, int n_from, size_t window, unsigned threshold, double ratio,
                   int32_t *match_from, uint32_t *match_dist) {

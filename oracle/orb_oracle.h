@@ -150,6 +150,17 @@ int oo_match_area(const oo_keypoint *kp_to, const uint8_t *desc_to, int n_to, co
                   const uint8_t *desc_from, int n_from, size_t window, unsigned threshold, double ratio,
                   int32_t *match_from, uint32_t *match_dist);
 
+/* DBoW2Handler::FastMatch candidate generation (handlers/DBoW2/dbo_w2_handler.cpp:25-72) with
+ * BowToIterator / BowToPointee (handlers/DBoW2/bow_to_iterator.{h,cpp}, bow_to_pointee.h:19-59): both feature
+ * vectors (DBoW2::FeatureVector = std::map<NodeId, std::vector<unsigned>>) are given in CSR form -- node ids
+ * ascending, ids of node k in ids[off[k] .. off[k+1]).  'to' ids are visited node by node over the nodes the two
+ * vectors share (merge join with lower_bound, bow_to_iterator.cpp:27-47); the candidates of a 'to' id are the
+ * 'from' ids of the same node in list order; then SNNMatcher::MatchWithIterators.  Returns the match count. */
+int oo_match_bow(const uint8_t *desc_to, int n_to, const uint8_t *desc_from, int n_from, const uint32_t *to_nodes,
+                 const int32_t *to_off, const uint32_t *to_ids, int n_to_nodes, const uint32_t *from_nodes,
+                 const int32_t *from_off, const uint32_t *from_ids, int n_from_nodes, unsigned threshold, double ratio,
+                 int32_t *match_from, uint32_t *match_dist);
+
 /* OrientationValidator::Validate validators/orientation_validator.cpp:16-97.
  * match_from[i] >= 0 are the matches (to i -> from match_from[i]); discarded ones are set to -1.
  * returns number discarded. */

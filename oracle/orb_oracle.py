@@ -258,6 +258,30 @@ def match_area(kp_to, desc_to, kp_from, desc_from, window=100, threshold=50, rat
     return mf[:len(kp_to)], md[:len(kp_to)]
 
 
+def match_bow(desc_to, desc_from, fv_to, fv_from, threshold=50, ratio=0.9):
+    """fv_to / fv_from: DBoW2::FeatureVector as {node id: [feature ids]} (any mapping; iterated in node order)."""
+    desc_to = np.ascontiguousarray(desc_to, np.uint8).reshape(-1, 32)
+    desc_from = np.ascontiguousarray(desc_from, np.uint8).reshape(-1, 32)
+
+    def csr(fv):
+        nodes = np.array(sorted(fv), np.uint32)
+        off = np.zeros(len(nodes) + 1, np.int32)
+        ids = []
+        for k, nd in enumerate(nodes.tolist()):
+            ids.extend(fv[nd])
+            off[k + 1] = len(ids)
+        return nodes, off, np.array(ids, np.uint32)
+
+    tn, to_, ti = csr(fv_to)
+    fn_, fo, fi = csr(fv_from)
+    mf = np.empty(max(len(desc_to), 1), np.int32)
+    md = np.zeros(max(len(desc_to), 1), np.uint32)
+    n = lib().oo_match_bow(_p(desc_to), len(desc_to), _p(desc_from), len(desc_from), _p(tn), _p(to_), _p(ti), len(tn),
+                           _p(fn_), _p(fo), _p(fi), len(fn_), C.c_uint(int(threshold)), C.c_double(ratio), _p(mf), _p(md))
+    assert n == int((mf[:len(desc_to)] >= 0).sum())
+    return mf[:len(desc_to)], md[:len(desc_to)]
+
+
 def orientation_validate(angle_to, angle_from, match_from):
     angle_to = np.ascontiguousarray(angle_to, np.float64)
     angle_from = np.ascontiguousarray(angle_from, np.float64)

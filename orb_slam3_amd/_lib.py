@@ -40,6 +40,12 @@ class WindowArgs(C.Structure):
                 ("ratio", C.c_double)]
 
 
+class GroupArgs(C.Structure):
+    _fields_ = [("to_desc", C.c_void_p), ("n_to", C.c_int32), ("from_desc", C.c_void_p), ("n_from", C.c_int32),
+                ("n_groups", C.c_int32), ("to_off", C.c_void_p), ("to_ids", C.c_void_p), ("from_off", C.c_void_p),
+                ("from_ids", C.c_void_p), ("threshold", C.c_uint32), ("ratio", C.c_double)]
+
+
 KP_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("angle", "<f4"), ("size", "<i4"), ("level", "<i4"), ("reserved", "<i4")])
 assert KP_DTYPE.itemsize == 32
 
@@ -47,7 +53,8 @@ assert KP_DTYPE.itemsize == 32
 EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_geometry", "orbgpu_stream",
            "orbgpu_synchronize", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
            "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_window",
-           "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_match_allpairs_device",
+           "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
+           "orbgpu_match_allpairs_device",
            "orbgpu_rotation_filter", "orbgpu_stage_times",
            "orbgpu_popcount_peak"]
 
@@ -80,6 +87,8 @@ def load():
         "orbgpu_match_window": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_window_device": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_frames_device": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, u64, u32, dbl, i32, vp, vp, vp]),
+        "orbgpu_match_groups": (i32, [vp, C.POINTER(GroupArgs), vp, vp]),
+        "orbgpu_match_groups_device": (i32, [vp, C.POINTER(GroupArgs), i32, vp, vp]),
         "orbgpu_match_allpairs_device": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, u32, dbl, i32, vp, vp]),
         "orbgpu_rotation_filter": (i32, [vp, vp, i32, vp, i32, vp, C.POINTER(i32)]),
         "orbgpu_stage_times": (i32, [vp, vp]),

@@ -733,6 +733,78 @@ int orbgpu_match_frames_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp, con
   return ORBGPU_OK;
 }
 
+int orbgpu_match_groups_device(orbgpu_ctx *ctx, const orbgpu_group_args *a, int32_t n_slots, int32_t *d_from_idx_per_to,
+                               uint32_t *d_dist) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_to < 0 || a->n_from < 0 || a->n_groups < 0 || n_slots < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (a->n_to == 0) return ORBGPU_OK;
+  if (!d_from_idx_per_to || !d_dist) return fail(ctx, ORBGPU_E_INVALID, "null output");
+  if (n_slots > 0 && (!a->to_desc || !a->from_desc || !a->to_off || !a->to_ids || !a->from_off || !a->from_ids || a->n_groups == 0))
+    return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = ensure_match_scratch(ctx, group_scratch_bytes(a->n_from, n_slots));
+  if (rc) return rc;
+  launch_match_groups(ctx, *a, n_slots, d_from_idx_per_to, d_dist, ctx->d_match_scratch);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
+int orbgpu_match_groups(orbgpu_ctx *ctx, const orbgpu_group_args *a, int32_t *from_idx_per_to, uint32_t *dist) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  int n_slots = 0, n_cand = 0;
+  orbgpu_group_args d{};
+  Staging st{ctx};
+  int32_t *d_idx = nullptr;
+  uint32_t *d_dist = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+    if (a->n_to < 0 || a->n_from < 0 || a->n_groups < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+    if (a->n_to == 0) return ORBGPU_OK;
+    if (!a->to_desc || !from_idx_per_to || !dist) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+    if (a->n_groups > 0) {
+      if (!a->to_off || !a->to_ids || !a->from_off || !a->from_ids || (a->n_from > 0 && !a->from_desc))
+        return fail(ctx, ORBGPU_E_INVALID, "null argument");
+      if (a->to_off[0] != 0 || a->from_off[0] != 0) return fail(ctx, ORBGPU_E_INVALID, "offsets must start at 0");
+      for (int g = 0; g < a->n_groups; g++)
+        if (a->to_off[g + 1] < a->to_off[g] || a->from_off[g + 1] < a->from_off[g])
+          return fail(ctx, ORBGPU_E_INVALID, "offsets must be non-decreasing");
+      n_slots = a->to_off[a->n_groups];
+      n_cand = a->from_off[a->n_groups];
+      for (int s = 0; s < n_slots; s++)
+        if (a->to_ids[s] >= (uint32_t)a->n_to) return fail(ctx, ORBGPU_E_INVALID, "'to' id outside [0, n_to)");
+      for (int c = 0; c < n_cand; c++)
+        if (a->from_ids[c] >= (uint32_t)a->n_from) return fail(ctx, ORBGPU_E_INVALID, "'from' id outside [0, n_from)");
+      if (n_cand >= (1 << 23)) return fail(ctx, ORBGPU_E_INVALID, "too many candidates");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nt = (size_t)a->n_to, nf = (size_t)a->n_from, ng = (size_t)a->n_groups;
+    int rc = st.reserve(pad256(nt * 32) + pad256(nf * 32) + 2 * pad256((ng + 1) * 4) + pad256((size_t)n_slots * 4) +
+                        pad256((size_t)n_cand * 4) + 2 * pad256(nt * 4) + 4096);
+    if (rc) return rc;
+    d = *a;
+    d.to_desc = st.put(a->to_desc, nt * 32);
+    d.from_desc = nf ? st.put(a->from_desc, nf * 32) : nullptr;
+    if (ng) {
+      d.to_off = st.put(a->to_off, ng + 1);
+      d.from_off = st.put(a->from_off, ng + 1);
+      d.to_ids = st.put(a->to_ids, (size_t)std::max(n_slots, 1));
+      d.from_ids = st.put(a->from_ids, (size_t)std::max(n_cand, 1));
+    }
+    d_idx = st.put<int32_t>(nullptr, nt);
+    d_dist = st.put<uint32_t>(nullptr, nt);
+  }
+  int rc = orbgpu_match_groups_device(ctx, &d, n_slots, d_idx, d_dist);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(hipMemcpyAsync(from_idx_per_to, d_idx, (size_t)a->n_to * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dist, d_dist, (size_t)a->n_to * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ORBGPU_OK;
+}
+
 int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
                                  const int32_t *d_n_rows, int32_t n_rows, const orbgpu_keypoint *d_kp_cols,
                                  const uint8_t *d_desc_cols, const int32_t *d_n_cols, int32_t n_cols, int32_t capacity,

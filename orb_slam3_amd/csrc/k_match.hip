@@ -480,6 +480,59 @@ __global__ __launch_bounds__(256) void k_link_fused(const orbgpu_keypoint *__res
 }
 
 // ------------------------------------------------------------------------------------------------
+// Node-grouped matching (DBoW2Handler::FastMatch, handlers/DBoW2/dbo_w2_handler.cpp:25-72; BowToIterator /
+// BowToPointee, bow_to_iterator.cpp:12-47, bow_to_pointee.h:37-45).  The caller has joined the two feature vectors:
+// group g holds the 'to' ids to_ids[to_off[g] .. to_off[g+1]) and the 'from' ids from_ids[from_off[g] ..) of one
+// vocabulary node, groups in node order.  One lane per visiting-order slot s; the candidates of a slot are its
+// group's 'from' ids in list order (key = distance << 23 | list position, so the first candidate wins ties).
+// Uniqueness: smallest distance, then the earliest slot -- the order MatchWithIterators visits the 'to' ids.
+__global__ __launch_bounds__(256) void k_group_scan(orbgpu_group_args a, int n_slots, int *__restrict__ slot_from,
+                                                    unsigned *__restrict__ slot_dist,
+                                                    unsigned long long *__restrict__ claim) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_slots) return;
+  // group of the slot: last g with to_off[g] <= s
+  int lo = 0, hi = a.n_groups;  // invariant: to_off[lo] <= s < to_off[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.to_off[mid] <= s) lo = mid; else hi = mid;
+  }
+  const int c0 = a.from_off[lo], c1 = a.from_off[lo + 1];
+  const uint4 *td = reinterpret_cast<const uint4 *>(a.to_desc) + 2 * (size_t)a.to_ids[s];
+  const uint4 t0 = td[0], t1 = td[1];
+  const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  const uint4 *fd = reinterpret_cast<const uint4 *>(a.from_desc);
+  unsigned best = KEY_NONE, second = KEY_NONE;
+  for (int c = c0; c < c1; c++) {
+    const unsigned j = a.from_ids[c];
+    const uint4 fa = fd[2 * (size_t)j], fb = fd[2 * (size_t)j + 1];
+    const unsigned key = (hamming8(t, fa, fb) << IDX_BITS) | (unsigned)(c - c0);
+    second = umed3(best, key, second);
+    best = min(best, key);
+  }
+  unsigned d = 0;
+  const int pos = snn_accept(best, second, a.threshold, a.ratio, d);
+  const int j = pos >= 0 ? (int)a.from_ids[c0 + pos] : -1;
+  slot_from[s] = j;
+  slot_dist[s] = d;
+  if (j >= 0) atomicMin(&claim[j], ((unsigned long long)d << 32) | (unsigned)s);
+}
+
+__global__ __launch_bounds__(256) void k_group_resolve(orbgpu_group_args a, int n_slots, const int *__restrict__ slot_from,
+                                                       const unsigned *__restrict__ slot_dist,
+                                                       const unsigned long long *__restrict__ claim,
+                                                       int *__restrict__ from_idx, unsigned *__restrict__ dist) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_slots) return;
+  const int j = slot_from[s];
+  if (j >= 0 && claim[j] == (((unsigned long long)slot_dist[s] << 32) | (unsigned)s)) {
+    const unsigned i = a.to_ids[s];
+    from_idx[i] = j;
+    dist[i] = slot_dist[s];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // All-pairs keyframe matching: 'to' = keyframe r of the row set, 'from' = keyframe c of the column set,
 // SNNMatcher::MatchWithIterators semantics with no candidate restriction (every 'from' in index order), then the
 // optional rotation histogram.  One workgroup owns one (r, c) pair from the scan to the match count, so nothing but
@@ -690,6 +743,26 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
                      capacity, d_to_frame, d_from_frame, n_chunks, partial, th, ratio, d_match, d_dist, claim);
   hipLaunchKernelGGL(k_link_resolve, dim3(n_pairs), dim3(256), 0, c->stream, d_kp, d_n, capacity, d_to_frame,
                      d_from_frame, claim, check_orientation, d_match, d_dist, d_n_matches);
+}
+
+size_t group_scratch_bytes(int n_from, int n_slots) { return (size_t)n_from * 8 + (size_t)n_slots * 8 + 256; }
+
+// d_from_idx / d_dist: n_to entries, set to -1 / 0 here; device_args holds device pointers
+void launch_match_groups(const orbgpu_ctx *c, const orbgpu_group_args &a, int n_slots, int *d_from_idx, unsigned *d_dist,
+                         void *scratch) {
+  unsigned long long *claim = reinterpret_cast<unsigned long long *>(scratch);
+  int *slot_from = reinterpret_cast<int *>(claim + a.n_from);
+  unsigned *slot_dist = reinterpret_cast<unsigned *>(slot_from + n_slots);
+  (void)hipMemsetAsync(d_from_idx, 0xff, (size_t)a.n_to * 4, c->stream);
+  (void)hipMemsetAsync(d_dist, 0, (size_t)a.n_to * 4, c->stream);
+  if (n_slots == 0 || a.n_from == 0) return;
+  (void)hipMemsetAsync(claim, 0xff, (size_t)a.n_from * 8, c->stream);
+  orbgpu_group_args b = a;
+  b.threshold = std::min(a.threshold, 256u);
+  const int blocks = (n_slots + 255) / 256;
+  hipLaunchKernelGGL(k_group_scan, dim3(blocks), dim3(256), 0, c->stream, b, n_slots, slot_from, slot_dist, claim);
+  hipLaunchKernelGGL(k_group_resolve, dim3(blocks), dim3(256), 0, c->stream, b, n_slots, slot_from, slot_dist, claim,
+                     d_from_idx, d_dist);
 }
 
 size_t allpairs_lds_bytes(int capacity) { return (size_t)capacity * 16; }

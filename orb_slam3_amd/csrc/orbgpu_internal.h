@@ -149,6 +149,9 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
                          int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
                          unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,
                          int *d_n_matches);
+size_t group_scratch_bytes(int n_from, int n_slots);
+void launch_match_groups(const orbgpu_ctx *c, const orbgpu_group_args &a, int n_slots, int *d_from_idx, unsigned *d_dist,
+                         void *scratch);
 size_t allpairs_lds_bytes(int capacity);
 void launch_match_allpairs(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
                            const int *d_n_rows, int n_rows, const orbgpu_keypoint *d_kp_cols, const uint8_t *d_desc_cols,

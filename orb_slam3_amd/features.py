@@ -262,6 +262,35 @@ class SNNMatcher:
                                from_xy=np.stack([kf["x"], kf["y"]], 1), from_level=kf["level"])
         return {i: int(j) for i, j in enumerate(idx) if j >= 0}
 
+    @staticmethod
+    def JoinFeatureVectors(fv_to, fv_from):
+        """Merge join of two DBoW2::FeatureVector maps ({node id: [feature ids]}) the way
+        BowToIterator::AdvanceUntilSameNode walks them (bow_to_iterator.cpp:27-47): nodes present in both, in node
+        order.  Returns (to_off, to_ids, from_off, from_ids) for orbgpu_match_groups."""
+        to_off, from_off, to_ids, from_ids = [0], [0], [], []
+        for node in sorted(set(fv_to) & set(fv_from)):
+            to_ids.extend(fv_to[node])
+            from_ids.extend(fv_from[node])
+            to_off.append(len(to_ids))
+            from_off.append(len(from_ids))
+        return (np.array(to_off, np.int32), np.array(to_ids, np.uint32), np.array(from_off, np.int32),
+                np.array(from_ids, np.uint32))
+
+    def MatchBow(self, to_desc, from_desc, fv_to, fv_from):
+        """SNNMatcher<BowToIterator>: the matcher of DBoW2Handler::FastMatch (dbo_w2_handler.cpp:25-72); candidates
+        of a 'to' feature are the 'from' features of the same vocabulary node."""
+        to_desc = np.ascontiguousarray(to_desc, np.uint8).reshape(-1, 32)
+        from_desc = np.ascontiguousarray(from_desc, np.uint8).reshape(-1, 32)
+        to_off, to_ids, from_off, from_ids = self.JoinFeatureVectors(fv_to, fv_from)
+        n_to = len(to_desc)
+        a = _lib.GroupArgs(_lib.ptr(to_desc), n_to, _lib.ptr(from_desc), len(from_desc), len(to_off) - 1,
+                           _lib.ptr(to_off), _lib.ptr(to_ids), _lib.ptr(from_off), _lib.ptr(from_ids), self.THRESHOLD_,
+                           self.nearest_neighbour_ratio_)
+        idx = np.full(max(n_to, 1), -1, np.int32)
+        dist = np.zeros(max(n_to, 1), np.uint32)
+        self._fe._check(self._lib.orbgpu_match_groups(self._fe.handle, C.byref(a), _lib.ptr(idx), _lib.ptr(dist)))
+        return {i: int(j) for i, j in enumerate(idx[:n_to]) if j >= 0}
+
 
 class OrientationValidator:
     """OrientationValidator(kp_to, kp_from).Validate(inout_matches_12) -> number discarded

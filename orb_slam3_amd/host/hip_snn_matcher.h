@@ -5,6 +5,7 @@
 // (descriptor, position, radius, level-range) arrays for ONE batched C-ABI call:
 //   * MatchArea       <- SNNMatcher<AreaToIterator>          (frame/monocular/monocular_frame.cpp:173-184)
 //   * MatchProjection <- SNNMatcher<ProjectionSearchIterator> (monocular_frame.cpp:285-306, monocular_key_frame.cpp:183-216,353-376)
+//   * MatchBow        <- SNNMatcher<BowToIterator>          (features/handlers/DBoW2/dbo_w2_handler.cpp:25-72)
 //   * HipOrientationValidator::Validate <- OrientationValidator::Validate (validators/orientation_validator.cpp:16-40)
 // Compiled inside the reference tree (includes its headers).  Results are the same unordered maps.
 #ifndef ORB_SLAM3_AMD_HIP_SNN_MATCHER_H_
@@ -12,6 +13,7 @@
 
 #include <algorithm>
 #include <list>
+#include <map>
 #include <stdexcept>
 #include <unordered_map>
 #include <vector>
@@ -76,6 +78,46 @@ class HipSNNMatcher {
     Fill(from, from_xy, flev);
     Run(to_desc.data(), nt, to_xy, win, lmin, lmax, nullptr, from, from_xy, flev,
         [&](size_t a, size_t j) { out_matches[ids[a]] = j; });
+  }
+
+  // DBoW2Handler::FastMatch's matcher: candidates of a 'to' feature are the 'from' features of the same vocabulary
+  // node.  FeatureVector is DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) or anything shaped like
+  // it; the merge join below is BowToIterator::AdvanceUntilSameNode (handlers/DBoW2/bow_to_iterator.cpp:27-47).
+  template <class FeatureVector>
+  void MatchBow(const FeatureVector & feature_vector_to, const FeatureVector & feature_vector_from, const Features & to,
+                const Features & from, std::unordered_map<std::size_t, std::size_t> & out_matches) const {
+    const size_t nt = to.Size(), nf = from.Size();
+    if (nt == 0) return;
+    std::vector<int32_t> to_off{0}, from_off{0};
+    std::vector<uint32_t> to_ids, from_ids;
+    auto it_to = feature_vector_to.begin();
+    auto it_from = feature_vector_from.begin();
+    while (it_to != feature_vector_to.end() && it_from != feature_vector_from.end()) {
+      if (it_to->first == it_from->first) {
+        to_ids.insert(to_ids.end(), it_to->second.begin(), it_to->second.end());
+        from_ids.insert(from_ids.end(), it_from->second.begin(), it_from->second.end());
+        to_off.push_back((int32_t)to_ids.size());
+        from_off.push_back((int32_t)from_ids.size());
+        ++it_to;
+        ++it_from;
+      } else if (it_to->first < it_from->first) {
+        it_to = feature_vector_to.lower_bound(it_from->first);
+      } else {
+        it_from = feature_vector_from.lower_bound(it_to->first);
+      }
+    }
+    orbgpu_group_args a{};
+    a.to_desc = to.descriptors.data(); a.n_to = (int32_t)nt;
+    a.from_desc = from.descriptors.data(); a.n_from = (int32_t)nf;
+    a.n_groups = (int32_t)to_off.size() - 1;
+    a.to_off = to_off.data(); a.to_ids = to_ids.data(); a.from_off = from_off.data(); a.from_ids = from_ids.data();
+    a.threshold = THRESHOLD_; a.ratio = nearest_neighbour_ratio_;
+    std::vector<int32_t> idx(nt);
+    std::vector<uint32_t> dist(nt);
+    if (orbgpu_match_groups(ctx_, &a, idx.data(), dist.data()) != ORBGPU_OK)
+      throw std::runtime_error(std::string("orbgpu_match_groups: ") + orbgpu_last_error(ctx_));
+    for (size_t i = 0; i < nt; ++i)
+      if (idx[i] >= 0) out_matches[i] = (size_t)idx[i];
   }
 
  private:

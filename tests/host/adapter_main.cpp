@@ -4,6 +4,7 @@
 #include <fstream>
 #include <sstream>
 #include <list>
+#include <map>
 #include <memory>
 
 #include "hip_orb_feature_extractor.h"
@@ -54,6 +55,14 @@ int main(int argc, char ** argv) {
   std::unordered_map<map::MapPoint *, std::size_t> proj;
   features::matching::HipSNNMatcher(hip->context(), 0.9, 100).MatchProjection(vis, f1, proj);
 
+  // DBoW2Handler::FastMatch(WEAK), dbo_w2_handler.cpp:25-72, with synthetic feature vectors: node = first
+  // descriptor byte mod 16 (the vocabulary itself is outside the path)
+  std::map<unsigned, std::vector<unsigned>> fv0, fv1;
+  for (size_t j = 0; j < f0.Size(); ++j) fv0[f0.descriptors.data()[32 * j] % 16u].push_back((unsigned)j);
+  for (size_t j = 0; j < f1.Size(); ++j) fv1[f1.descriptors.data()[32 * j] % 16u].push_back((unsigned)j);
+  std::unordered_map<std::size_t, std::size_t> bow;
+  features::matching::HipSNNMatcher(hip->context(), 0.9, 100).MatchBow(fv1, fv0, f1, f0, bow);
+
   std::ofstream o(argv[6], std::ios::binary);
   for (const features::Features * f : {&f0, &f1}) {
     put(o, (int32_t)f->Size());
@@ -64,6 +73,8 @@ int main(int argc, char ** argv) {
   for (const auto & kv : matches) { put(o, (int32_t)kv.first); put(o, (int32_t)kv.second); }
   put(o, (int32_t)proj.size());
   for (const auto & kv : proj) { put(o, (int32_t)(kv.first - mps.data())); put(o, (int32_t)kv.second); }
+  put(o, (int32_t)bow.size());
+  for (const auto & kv : bow) { put(o, (int32_t)kv.first); put(o, (int32_t)kv.second); }
   // scalar helpers
   put(o, (uint32_t)fe->PredictScale(1.0, 3.0)); put(o, fe->GetAcceptableSquareError(3));
   features::DescriptorType a, b; std::memcpy(a.d, f0.descriptors.data(), 32); std::memcpy(b.d, f0.descriptors.data() + 32, 32);

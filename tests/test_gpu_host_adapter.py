@@ -75,6 +75,15 @@ def test_cpp_adapter_end_to_end(oracle, tmp_path):
                               to_min_level=np.maximum(lv - 1, 0), to_max_level=lv + 1,
                               from_xy=np.stack([k1["x"], k1["y"]], 1), from_level=k1["level"])
     assert proj == {int(sel[i]): int(j) for i, j in enumerate(omf) if j >= 0} and len(proj) > 20
+    n_bow = take("i")
+    bow = dict(take("ii") for _ in range(n_bow))
+    fv0, fv1 = {}, {}
+    for j in range(len(d0)):
+        fv0.setdefault(int(d0[j, 0]) % 16, []).append(j)
+    for j in range(len(d1)):
+        fv1.setdefault(int(d1[j, 0]) % 16, []).append(j)
+    omb, _ = oracle.match_bow(d1, d0, fv1, fv0, 100, 0.9)
+    assert bow == {i: int(j) for i, j in enumerate(omb) if j >= 0} and len(bow) > 5
     assert take("I") == oracle.predict_scale(1.0, 3.0, 1.2, 8)
     s3 = 1.0 * 1.2 * 1.2 * 1.2
     assert take("d") == s3 * s3

@@ -162,3 +162,64 @@ def test_extract_then_link_end_to_end(oracle):
     assert got == _as_dict(omf) and nd == ond
     assert len(got) >= 100  # the reference needs >= 100 matches to link (monocular_frame.cpp:195)
     fe.close()
+
+
+def _feature_vectors(rng, to, frm, n_nodes):
+    """synthetic DBoW2::FeatureVector maps: node mostly decided by the descriptor, so planted pairs share a node"""
+    node_of = lambda d: int(d[0]) % n_nodes
+    fv_to, fv_from = {}, {}
+    for i in range(len(to)):
+        nd = node_of(to[i]) if rng.random() < 0.9 else int(rng.integers(0, n_nodes))
+        fv_to.setdefault(2 * nd + (1 if rng.random() < 0.05 else 0), []).append(i)
+    for j in range(len(frm)):
+        nd = node_of(frm[j]) if rng.random() < 0.9 else int(rng.integers(0, n_nodes))
+        fv_from.setdefault(2 * nd + (1 if rng.random() < 0.05 else 0), []).append(j)
+    return fv_to, fv_from
+
+
+@pytest.mark.parametrize("n_to,n_from,n_nodes", [(1, 1, 1), (300, 280, 7), (1000, 1000, 100), (2500, 900, 3), (64, 4000, 40)])
+def test_bow_group_parity(oracle, fe, n_to, n_from, n_nodes):
+    """orbgpu_match_groups (DBoW2Handler::FastMatch's node-restricted matcher) against the oracle for the three
+    severities of dbo_w2_handler.cpp:37-51, followed by the rotation filter as in :68-71."""
+    from orb_slam3_amd.features import SNNMatcher, OrientationValidator
+    rng = np.random.default_rng(n_to + n_from)
+    frm = synth.descriptors(300 + n_from, n_from)
+    to = synth.descriptors(400 + n_to, n_to, planted_from=frm, planted_frac=0.6, max_flips=70)
+    if n_to > 10 and n_from > 12:
+        to[5] = to[4]
+        frm[11] = frm[10]
+    fv_to, fv_from = _feature_vectors(rng, to, frm, n_nodes)
+    fv_to[2 * n_nodes + 10] = []                 # shared node with an empty 'to' list (bow_to_iterator.cpp:31-35)
+    fv_from[2 * n_nodes + 10] = [0]
+    fv_to[2 * n_nodes + 20] = [0] if 0 not in sum(fv_to.values(), []) else []   # node only on the 'to' side
+    ang_to = rng.choice([5.0, 37.0, 181.0, 359.0], n_to).astype(np.float32)
+    ang_from = rng.choice([5.0, 36.0, 180.0, 2.0], n_from).astype(np.float32)
+    for th, ratio in ((50, 0.6), (50, 0.7), (100, 0.9)):
+        omf, _ = oracle.match_bow(to, frm, fv_to, fv_from, th, ratio)
+        got = SNNMatcher(ratio, th, fe).MatchBow(to, frm, fv_to, fv_from)
+        assert got == _as_dict(omf)
+        ov, _ = oracle.orientation_validate(ang_to, ang_from, omf)
+        from orb_slam3_amd._lib import KP_DTYPE
+        kt, kf = np.zeros(n_to, KP_DTYPE), np.zeros(n_from, KP_DTYPE)
+        kt["angle"], kf["angle"] = ang_to, ang_from
+        OrientationValidator(kt, kf, fe).Validate(got)
+        assert got == _as_dict(ov)
+
+
+def test_bow_group_errors(fe):
+    from orb_slam3_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    d = np.zeros((4, 32), np.uint8)
+    idx, dist = np.zeros(4, np.int32), np.zeros(4, np.uint32)
+    off = np.array([0, 2], np.int32)
+    ids = np.array([0, 9], np.uint32)      # 9 is outside [0, 4)
+    a = _lib.GroupArgs(_lib.ptr(d), 4, _lib.ptr(d), 4, 1, _lib.ptr(off), _lib.ptr(ids), _lib.ptr(off), _lib.ptr(ids), 50, 0.9)
+    assert lib.orbgpu_match_groups(fe.handle, C.byref(a), _lib.ptr(idx), _lib.ptr(dist)) == _lib.E_INVALID
+    bad = np.array([0, 2, 1], np.int32)    # decreasing offsets
+    ok_ids = np.array([0, 1], np.uint32)
+    a = _lib.GroupArgs(_lib.ptr(d), 4, _lib.ptr(d), 4, 2, _lib.ptr(bad), _lib.ptr(ok_ids), _lib.ptr(bad), _lib.ptr(ok_ids), 50, 0.9)
+    assert lib.orbgpu_match_groups(fe.handle, C.byref(a), _lib.ptr(idx), _lib.ptr(dist)) == _lib.E_INVALID
+    a = _lib.GroupArgs(_lib.ptr(d), 4, _lib.ptr(d), 4, 0, None, None, None, None, 50, 0.9)   # no shared node: no matches
+    assert lib.orbgpu_match_groups(fe.handle, C.byref(a), _lib.ptr(idx), _lib.ptr(dist)) == 0
+    assert (idx == -1).all()

@@ -321,3 +321,80 @@ def test_predict_scale(oracle):
         e = max(0.0, math.ceil(math.log(m / d) / ls))
         e = min(int(e), 7)
         assert oracle.predict_scale(d, m, 1.2, 8) == e
+
+
+def _literal_bow_match(desc_to, desc_from, fv_to, fv_from, threshold, ratio, ham):
+    """Line-by-line transcription of BowToIterator (bow_to_iterator.cpp:12-47) driving
+    SNNMatcher::MatchWithIterators (second_nearest_neighbor_matcher.hpp:30-80) on dict-based feature vectors."""
+    import bisect
+    to_nodes, from_nodes = sorted(fv_to), sorted(fv_from)
+    kt = kf = 0
+    matches, best_matches, best_dist = {}, {}, {}
+    while kt < len(to_nodes) and kf < len(from_nodes):      # AdvanceUntilSameNode
+        if to_nodes[kt] == from_nodes[kf]:
+            ids = fv_to[to_nodes[kt]]
+            if not ids:
+                kt += 1
+                kf += 1
+                continue
+            for i in ids:                                     # operator++ inside one node
+                best = second = 0xFFFFFFFF
+                best_j = None
+                for j in fv_from[from_nodes[kf]]:
+                    d = ham(desc_to[i], desc_from[j])
+                    if d > threshold:
+                        continue
+                    if d < best:
+                        best_j, second, best = j, best, d
+                    elif d < second:
+                        second = d
+                if best < ratio * second:
+                    if best_j in best_matches:
+                        if best_dist[best_j] > best:
+                            del matches[best_matches[best_j]]
+                        else:
+                            continue
+                    best_dist[best_j] = best
+                    best_matches[best_j] = i
+                    matches[i] = best_j
+            kt += 1
+            kf += 1
+        elif to_nodes[kt] < from_nodes[kf]:
+            kt = bisect.bisect_left(to_nodes, from_nodes[kf])
+        else:
+            kf = bisect.bisect_left(from_nodes, to_nodes[kt])
+    return matches
+
+
+def test_match_bow_vs_literal(oracle):
+    from orb_slam3_amd import synth
+    rng = np.random.default_rng(21)
+    for trial in range(6):
+        n_from, n_to = int(rng.integers(40, 400)), int(rng.integers(40, 400))
+        frm = synth.descriptors(100 + trial, n_from)
+        to = synth.descriptors(200 + trial, n_to, planted_from=frm, planted_frac=0.6)
+        n_nodes = int(rng.integers(3, 40))
+        # node of a feature: mostly a function of the descriptor (so planted pairs share a node), some noise, some
+        # nodes present on one side only, and an occasional empty 'to' list
+        node_of = lambda d: int(d[0]) % n_nodes
+        fv_to, fv_from = {}, {}
+        for i in range(n_to):
+            nd = node_of(to[i]) if rng.random() < 0.9 else int(rng.integers(0, n_nodes))
+            fv_to.setdefault(2 * nd + (1 if rng.random() < 0.05 else 0), []).append(i)
+        for j in range(n_from):
+            nd = node_of(frm[j]) if rng.random() < 0.9 else int(rng.integers(0, n_nodes))
+            fv_from.setdefault(2 * nd + (1 if rng.random() < 0.05 else 0), []).append(j)
+        if trial % 2:
+            fv_to[2 * n_nodes + 4] = []
+            fv_from[2 * n_nodes + 4] = [0, 1]
+        # duplicate rows so that ties (best == second, equal-distance claims) occur
+        to[1] = to[0]
+        frm[3] = frm[2]
+        ham = lambda a, b: int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+        for th, ratio in ((50, 0.6), (50, 0.7), (100, 0.9)):
+            want = _literal_bow_match(to, frm, fv_to, fv_from, th, ratio, ham)
+            mf, md = oracle.match_bow(to, frm, fv_to, fv_from, th, ratio)
+            got = {i: int(j) for i, j in enumerate(mf) if j >= 0}
+            assert got == want
+            for i, j in got.items():
+                assert md[i] == ham(to[i], frm[j])
