@@ -225,6 +225,27 @@ int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_ro
 int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to, const float *angle_from,
                            int32_t n_from, int32_t *match, int32_t *n_discarded);
 
+/* ---- vocabulary (bag of words) ------------------------------------------------------------------ */
+/* replaces: the per-feature tree descent of DBoW2Handler::Precompute (features/handlers/DBoW2/
+ * dbo_w2_handler.cpp:74-93) = TemplatedVocabulary<FORB>::transform(feature, word_id, weight, nid, levelsup)
+ * (DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259) with FORB::distance (DBoW2/DBoW2/FORB.cpp:81-101).
+ * The tree is passed flat, as m_nodes holds it: node 0 is the root, the children of node v are
+ * children[child_off[v] .. child_off[v+1]) in Node::children order (a leaf has none), node_desc is
+ * n_nodes x 32 bytes, word_id[v] = Node::word_id (read for leaves only), levels = m_L.  The arrays are copied
+ * to the context's device; the handle must be destroyed before the context.  Weights, the BowVector
+ * accumulation / normalisation and FeatureVector::addFeature stay on the host (TemplatedVocabulary.h:1125-1189;
+ * see orb_slam3_amd/host/hip_bow_vocabulary.h): they are map operations in double on a few hundred words. */
+typedef struct orbgpu_vocab orbgpu_vocab;
+int orbgpu_vocab_create(orbgpu_ctx *ctx, int32_t n_nodes, const int32_t *child_off, const uint32_t *children,
+                        const uint8_t *node_desc, const uint32_t *word_id, int32_t levels, orbgpu_vocab **out);
+void orbgpu_vocab_destroy(orbgpu_vocab *vocab);
+/* word_id_out[i] = leaf word of descriptor i, node_id_out[i] = its ancestor at level (levels - levelsup), the
+ * root (0) when that level is <= 0.  Host pointers; the _device form takes device pointers and is asynchronous. */
+int orbgpu_bow_transform(orbgpu_ctx *ctx, const orbgpu_vocab *vocab, const uint8_t *desc, int32_t n, int32_t levelsup,
+                         uint32_t *word_id_out, uint32_t *node_id_out);
+int orbgpu_bow_transform_device(orbgpu_ctx *ctx, const orbgpu_vocab *vocab, const uint8_t *d_desc, int32_t n,
+                                int32_t levelsup, uint32_t *d_word_id_out, uint32_t *d_node_id_out);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-stage GPU time in milliseconds (HIP events on the context's stream), averaged over the extract calls
  * enqueued since the last orbgpu_synchronize / orbgpu_stage_times (at most the last 32); waits for the stream.

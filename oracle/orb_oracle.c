@@ -972,6 +972,35 @@ int oo_snn_match(const oo_match_args *a, int32_t *match_from, uint32_t *match_di
   return nmatches;
 }
 
+void oo_bow_transform(const uint8_t *desc, int n, const int32_t *child_off, const uint32_t *children,
+                      const uint8_t *node_desc, const uint32_t *word_id, int L, int levelsup, uint32_t *out_word,
+                      uint32_t *out_node) {
+  const int nid_level = L - levelsup; /* :1226 */
+  for (int i = 0; i < n; i++) {
+    const uint8_t *f = desc + (size_t)i * 32;
+    uint32_t nid = 0; /* root when nid_level <= 0, :1227 */
+    uint32_t final_id = 0;
+    int current_level = 0;
+    do {
+      ++current_level;
+      const int c0 = child_off[final_id], c1 = child_off[final_id + 1];
+      final_id = children[c0];
+      double best_d = (double)oo_hamming256(f, node_desc + (size_t)final_id * 32);
+      for (int c = c0 + 1; c < c1; c++) {
+        const uint32_t id = children[c];
+        const double d = (double)oo_hamming256(f, node_desc + (size_t)id * 32);
+        if (d < best_d) {
+          best_d = d;
+          final_id = id;
+        }
+      }
+      if (current_level == nid_level) nid = final_id;
+    } while (child_off[final_id + 1] > child_off[final_id]); /* !isLeaf() */
+    out_word[i] = word_id[final_id];
+    out_node[i] = nid;
+  }
+}
+
 /* lower_bound over ascending node ids: first k in [lo, n) with nodes[k] >= key (std::map::lower_bound) */
 static int node_lower_bound(const uint32_t *nodes, int lo, int n, uint32_t key) {
   int k = lo;

@@ -150,6 +150,15 @@ int oo_match_area(const oo_keypoint *kp_to, const uint8_t *desc_to, int n_to, co
                   const uint8_t *desc_from, int n_from, size_t window, unsigned threshold, double ratio,
                   int32_t *match_from, uint32_t *match_dist);
 
+/* TemplatedVocabulary<FORB>::transform for one feature (DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259) with
+ * FORB::distance (DBoW2/DBoW2/FORB.cpp:81-101), for every row of desc.  The tree is given flat: the children of
+ * node v are children[child_off[v] .. child_off[v+1]) in the order of Node::children (a leaf has none), node 0 is
+ * the root, node_desc is n_nodes x 32, word_id[v] is Node::word_id of a leaf.  out_node receives the ancestor at
+ * level L - levelsup (0 = root when that level is <= 0), as transform's nid. */
+void oo_bow_transform(const uint8_t *desc, int n, const int32_t *child_off, const uint32_t *children,
+                      const uint8_t *node_desc, const uint32_t *word_id, int L, int levelsup, uint32_t *out_word,
+                      uint32_t *out_node);
+
 /* DBoW2Handler::FastMatch candidate generation (handlers/DBoW2/dbo_w2_handler.cpp:25-72) with
  * BowToIterator / BowToPointee (handlers/DBoW2/bow_to_iterator.{h,cpp}, bow_to_pointee.h:19-59): both feature
  * vectors (DBoW2::FeatureVector = std::map<NodeId, std::vector<unsigned>>) are given in CSR form -- node ids

@@ -258,6 +258,19 @@ def match_area(kp_to, desc_to, kp_from, desc_from, window=100, threshold=50, rat
     return mf[:len(kp_to)], md[:len(kp_to)]
 
 
+def bow_transform(desc, child_off, children, node_desc, word_id, L, levelsup=4):
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    child_off = np.ascontiguousarray(child_off, np.int32)
+    children = np.ascontiguousarray(children, np.uint32)
+    node_desc = np.ascontiguousarray(node_desc, np.uint8).reshape(-1, 32)
+    word_id = np.ascontiguousarray(word_id, np.uint32)
+    ow = np.zeros(max(len(desc), 1), np.uint32)
+    on = np.zeros(max(len(desc), 1), np.uint32)
+    lib().oo_bow_transform(_p(desc), len(desc), _p(child_off), _p(children), _p(node_desc), _p(word_id), int(L),
+                           int(levelsup), _p(ow), _p(on))
+    return ow[:len(desc)], on[:len(desc)]
+
+
 def match_bow(desc_to, desc_from, fv_to, fv_from, threshold=50, ratio=0.9):
     """fv_to / fv_from: DBoW2::FeatureVector as {node id: [feature ids]} (any mapping; iterated in node order)."""
     desc_to = np.ascontiguousarray(desc_to, np.uint8).reshape(-1, 32)

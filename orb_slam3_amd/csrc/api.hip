@@ -805,6 +805,92 @@ int orbgpu_match_groups(orbgpu_ctx *ctx, const orbgpu_group_args *a, int32_t *fr
   return ORBGPU_OK;
 }
 
+int orbgpu_vocab_create(orbgpu_ctx *ctx, int32_t n_nodes, const int32_t *child_off, const uint32_t *children,
+                        const uint8_t *node_desc, const uint32_t *word_id, int32_t levels, orbgpu_vocab **out) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!out) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  *out = nullptr;
+  if (n_nodes < 1 || levels < 0 || !child_off || !node_desc || !word_id) return fail(ctx, ORBGPU_E_INVALID, "bad vocabulary");
+  if (child_off[0] != 0) return fail(ctx, ORBGPU_E_INVALID, "child_off must start at 0");
+  for (int v = 0; v < n_nodes; v++)
+    if (child_off[v + 1] < child_off[v]) return fail(ctx, ORBGPU_E_INVALID, "child_off must be non-decreasing");
+  const int n_children = child_off[n_nodes];
+  if (n_children > 0 && !children) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  for (int c = 0; c < n_children; c++)
+    if (children[c] == 0 || children[c] >= (uint32_t)n_nodes) return fail(ctx, ORBGPU_E_INVALID, "child id outside (0, n_nodes)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  orbgpu_vocab *v = new orbgpu_vocab;
+  v->ctx = ctx;
+  v->n_nodes = n_nodes;
+  v->levels = levels;
+  auto bail = [&](hipError_t e) {
+    orbgpu_vocab_destroy(v);
+    return fail_hip(ctx, e, "vocabulary upload", __FILE__, __LINE__);
+  };
+  hipError_t e;
+  if ((e = dmalloc(&v->d_child_off, (size_t)n_nodes + 1)) != hipSuccess) return bail(e);
+  if ((e = dmalloc(&v->d_children, (size_t)std::max(n_children, 1))) != hipSuccess) return bail(e);
+  if ((e = dmalloc(&v->d_node_desc, (size_t)n_nodes * 32)) != hipSuccess) return bail(e);
+  if ((e = dmalloc(&v->d_word_id, (size_t)n_nodes)) != hipSuccess) return bail(e);
+  if ((e = hipMemcpy(v->d_child_off, child_off, ((size_t)n_nodes + 1) * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+  if (n_children && (e = hipMemcpy(v->d_children, children, (size_t)n_children * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+  if ((e = hipMemcpy(v->d_node_desc, node_desc, (size_t)n_nodes * 32, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+  if ((e = hipMemcpy(v->d_word_id, word_id, (size_t)n_nodes * 4, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+  *out = v;
+  return ORBGPU_OK;
+}
+
+void orbgpu_vocab_destroy(orbgpu_vocab *v) {
+  if (!v) return;
+  if (v->ctx) (void)hipSetDevice(v->ctx->device);
+  void *ptrs[] = {v->d_child_off, v->d_children, v->d_node_desc, v->d_word_id};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  delete v;
+}
+
+int orbgpu_bow_transform_device(orbgpu_ctx *ctx, const orbgpu_vocab *vocab, const uint8_t *d_desc, int32_t n, int32_t levelsup,
+                                uint32_t *d_word_id_out, uint32_t *d_node_id_out) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!vocab || vocab->ctx != ctx) return fail(ctx, ORBGPU_E_INVALID, "vocabulary belongs to another context");
+  if (n < 0 || levelsup < 0) return fail(ctx, ORBGPU_E_INVALID, "negative argument");
+  if (n == 0) return ORBGPU_OK;
+  if (!d_desc || !d_word_id_out || !d_node_id_out) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  launch_bow_transform(ctx, vocab, d_desc, n, levelsup, d_word_id_out, d_node_id_out);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
+int orbgpu_bow_transform(orbgpu_ctx *ctx, const orbgpu_vocab *vocab, const uint8_t *desc, int32_t n, int32_t levelsup,
+                         uint32_t *word_id_out, uint32_t *node_id_out) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  if (n < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (n == 0) return ORBGPU_OK;
+  if (!desc || !word_id_out || !node_id_out) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  Staging st{ctx};
+  uint8_t *d_desc;
+  uint32_t *d_w, *d_n;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = st.reserve(pad256((size_t)n * 32) + 2 * pad256((size_t)n * 4) + 1024);
+    if (rc) return rc;
+    d_desc = st.put(desc, (size_t)n * 32);
+    d_w = st.put<uint32_t>(nullptr, (size_t)n);
+    d_n = st.put<uint32_t>(nullptr, (size_t)n);
+  }
+  int rc = orbgpu_bow_transform_device(ctx, vocab, d_desc, n, levelsup, d_w, d_n);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(hipMemcpyAsync(word_id_out, d_w, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(node_id_out, d_n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ORBGPU_OK;
+}
+
 int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
                                  const int32_t *d_n_rows, int32_t n_rows, const orbgpu_keypoint *d_kp_cols,
                                  const uint8_t *d_desc_cols, const int32_t *d_n_cols, int32_t n_cols, int32_t capacity,

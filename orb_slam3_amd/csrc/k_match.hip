@@ -533,6 +533,45 @@ __global__ __launch_bounds__(256) void k_group_resolve(orbgpu_group_args a, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Vocabulary tree descent: TemplatedVocabulary<FORB>::transform for one feature
+// (DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259) with FORB::distance (FORB.cpp:81-101).  One lane per descriptor; at
+// every level the lane scans the children of its current node in Node::children order and keeps the first minimum
+// (strict <, :1243).  node_out = the ancestor at level L - levelsup (root when that is <= 0).
+__global__ __launch_bounds__(256) void k_bow_transform(const uint8_t *__restrict__ desc, int n,
+                                                       const int *__restrict__ child_off,
+                                                       const unsigned *__restrict__ children,
+                                                       const uint8_t *__restrict__ node_desc,
+                                                       const unsigned *__restrict__ word_id, int nid_level, int max_depth,
+                                                       unsigned *__restrict__ word_out, unsigned *__restrict__ node_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint4 *td = reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)i;
+  const uint4 t0 = td[0], t1 = td[1];
+  const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  const uint4 *nd = reinterpret_cast<const uint4 *>(node_desc);
+  unsigned cur = 0, nid = 0;
+  int level = 0;
+  int c0 = child_off[0], c1 = child_off[1];
+  while (c1 > c0 && level < max_depth) {  // max_depth bounds the walk on a malformed (cyclic) tree
+    ++level;
+    unsigned best = 0xffffffffu;
+    for (int c = c0; c < c1; c++) {
+      const unsigned id = children[c];
+      const unsigned d = hamming8(t, nd[2 * (size_t)id], nd[2 * (size_t)id + 1]);
+      if (d < best) {
+        best = d;
+        cur = id;
+      }
+    }
+    if (level == nid_level) nid = cur;
+    c0 = child_off[cur];
+    c1 = child_off[cur + 1];
+  }
+  word_out[i] = word_id[cur];
+  node_out[i] = nid;
+}
+
+// ------------------------------------------------------------------------------------------------
 // All-pairs keyframe matching: 'to' = keyframe r of the row set, 'from' = keyframe c of the column set,
 // SNNMatcher::MatchWithIterators semantics with no candidate restriction (every 'from' in index order), then the
 // optional rotation histogram.  One workgroup owns one (r, c) pair from the scan to the match count, so nothing but
@@ -763,6 +802,13 @@ void launch_match_groups(const orbgpu_ctx *c, const orbgpu_group_args &a, int n_
   hipLaunchKernelGGL(k_group_scan, dim3(blocks), dim3(256), 0, c->stream, b, n_slots, slot_from, slot_dist, claim);
   hipLaunchKernelGGL(k_group_resolve, dim3(blocks), dim3(256), 0, c->stream, b, n_slots, slot_from, slot_dist, claim,
                      d_from_idx, d_dist);
+}
+
+void launch_bow_transform(const orbgpu_ctx *c, const orbgpu_vocab *v, const uint8_t *d_desc, int n, int levelsup,
+                          unsigned *d_word, unsigned *d_node) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_desc, n, v->d_child_off,
+                     v->d_children, v->d_node_desc, v->d_word_id, v->levels - levelsup, v->n_nodes, d_word, d_node);
 }
 
 size_t allpairs_lds_bytes(int capacity) { return (size_t)capacity * 16; }

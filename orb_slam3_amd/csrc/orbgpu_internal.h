@@ -121,6 +121,16 @@ struct orbgpu_ctx {
   int last_feature_count = 0;
 };
 
+// a vocabulary tree resident on the device of the context that created it
+struct orbgpu_vocab {
+  orbgpu_ctx *ctx = nullptr;
+  int n_nodes = 0, levels = 0;
+  int *d_child_off = nullptr;        // [n_nodes + 1]
+  unsigned *d_children = nullptr;    // [child_off[n_nodes]]
+  uint8_t *d_node_desc = nullptr;    // [n_nodes][32]
+  unsigned *d_word_id = nullptr;     // [n_nodes]
+};
+
 int fail(orbgpu_ctx *ctx, int code, const std::string &msg);
 int fail_hip(orbgpu_ctx *ctx, hipError_t e, const char *expr, const char *file, int line);
 
@@ -152,6 +162,8 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
 size_t group_scratch_bytes(int n_from, int n_slots);
 void launch_match_groups(const orbgpu_ctx *c, const orbgpu_group_args &a, int n_slots, int *d_from_idx, unsigned *d_dist,
                          void *scratch);
+void launch_bow_transform(const orbgpu_ctx *c, const orbgpu_vocab *v, const uint8_t *d_desc, int n, int levelsup,
+                          unsigned *d_word, unsigned *d_node);
 size_t allpairs_lds_bytes(int capacity);
 void launch_match_allpairs(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
                            const int *d_n_rows, int n_rows, const orbgpu_keypoint *d_kp_cols, const uint8_t *d_desc_cols,

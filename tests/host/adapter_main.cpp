@@ -1,5 +1,6 @@
 // Drives the C++ adapters (orb_slam3_amd/host/) the way the reference's callers do and dumps the results for
 // tests/test_gpu_host_adapter.py to compare with the oracle.  usage: adapter_test W H NFEAT img0.raw img1.raw out.bin
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <sstream>
@@ -9,8 +10,26 @@
 
 #include "hip_orb_feature_extractor.h"
 #include "hip_snn_matcher.h"
+#include "hip_bow_vocabulary.h"
 
 using namespace orb_slam3;
+
+// stand-ins for DBoW2::BowVector / DBoW2::FeatureVector (BowVector.cpp:34-84, FeatureVector.cpp:33-47): the
+// adapter only needs their public operations
+struct TestBowVector : std::map<unsigned, double> {
+  enum { kL1, kL2 };
+  void addWeight(unsigned id, double v) { auto it = lower_bound(id); if (it != end() && it->first == id) it->second += v; else insert(it, {id, v}); }
+  void addIfNotExist(unsigned id, double v) { auto it = lower_bound(id); if (it == end() || it->first != id) insert(it, {id, v}); }
+  void normalize(int type) {
+    double norm = 0.0;
+    if (type == kL1) { for (auto & kv : *this) norm += std::fabs(kv.second); }
+    else { for (auto & kv : *this) norm += kv.second * kv.second; norm = std::sqrt(norm); }
+    if (norm > 0.0) for (auto & kv : *this) kv.second /= norm;
+  }
+};
+struct TestFeatureVector : std::map<unsigned, std::vector<unsigned>> {
+  void addFeature(unsigned id, unsigned i) { (*this)[id].push_back(i); }
+};
 
 static TImageGray8U load(const char * path, int w, int h) {
   TImageGray8U img;
@@ -63,6 +82,32 @@ int main(int argc, char ** argv) {
   std::unordered_map<std::size_t, std::size_t> bow;
   features::matching::HipSNNMatcher(hip->context(), 0.9, 100).MatchBow(fv1, fv0, f1, f0, bow);
 
+  // DBoW2Handler::Precompute, dbo_w2_handler.cpp:74-93, on a small regular vocabulary (k = 4, L = 3) whose node
+  // descriptors are rows of frame 0's descriptor matrix (the test rebuilds the same tree)
+  std::vector<int32_t> child_off{0};
+  std::vector<uint32_t> children, word_id;
+  std::vector<uint8_t> node_desc;
+  std::vector<double> weight;
+  {
+    const int k = 4, L = 3;
+    int n_nodes = 0, width = 1;
+    for (int l = 0; l <= L; ++l) { n_nodes += width; width *= k; }
+    int next = 1, first_leaf = n_nodes - width / k;
+    for (int v = 0; v < n_nodes; ++v) {
+      if (v < first_leaf) for (int c = 0; c < k; ++c) children.push_back((uint32_t)next++);
+      child_off.push_back((int32_t)children.size());
+      const uint8_t * src = f0.descriptors.data() + 32 * (size_t)(v % f0.Size());
+      node_desc.insert(node_desc.end(), src, src + 32);
+      word_id.push_back(v >= first_leaf ? (uint32_t)(v - first_leaf) : 0u);
+      weight.push_back(v % 7 == 3 ? 0.0 : 0.5 + 0.25 * (v % 5));
+    }
+  }
+  features::handlers::HipBowVocabulary voc(hip->context(), child_off, children, node_desc, word_id, weight, 3,
+                                           features::handlers::HipBowWeighting::TF_IDF, features::handlers::HipBowNorm::L1);
+  TestBowVector bv;
+  TestFeatureVector tfv;
+  voc.transform(f1.descriptors.data(), f1.Size(), bv, tfv, 2);
+
   std::ofstream o(argv[6], std::ios::binary);
   for (const features::Features * f : {&f0, &f1}) {
     put(o, (int32_t)f->Size());
@@ -75,6 +120,10 @@ int main(int argc, char ** argv) {
   for (const auto & kv : proj) { put(o, (int32_t)(kv.first - mps.data())); put(o, (int32_t)kv.second); }
   put(o, (int32_t)bow.size());
   for (const auto & kv : bow) { put(o, (int32_t)kv.first); put(o, (int32_t)kv.second); }
+  put(o, (int32_t)bv.size());
+  for (const auto & kv : bv) { put(o, (int32_t)kv.first); put(o, kv.second); }
+  put(o, (int32_t)tfv.size());
+  for (const auto & kv : tfv) { put(o, (int32_t)kv.first); put(o, (int32_t)kv.second.size()); for (unsigned i : kv.second) put(o, (int32_t)i); }
   // scalar helpers
   put(o, (uint32_t)fe->PredictScale(1.0, 3.0)); put(o, fe->GetAcceptableSquareError(3));
   features::DescriptorType a, b; std::memcpy(a.d, f0.descriptors.data(), 32); std::memcpy(b.d, f0.descriptors.data() + 32, 32);

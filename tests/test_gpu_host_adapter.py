@@ -84,6 +84,38 @@ def test_cpp_adapter_end_to_end(oracle, tmp_path):
         fv1.setdefault(int(d1[j, 0]) % 16, []).append(j)
     omb, _ = oracle.match_bow(d1, d0, fv1, fv0, 100, 0.9)
     assert bow == {i: int(j) for i, j in enumerate(omb) if j >= 0} and len(bow) > 5
+    # HipBowVocabulary::transform on the k = 4, L = 3 vocabulary adapter_main.cpp builds from frame 0's descriptors
+    k, L = 4, 3
+    n_nodes = sum(k ** l for l in range(L + 1))
+    first_leaf = n_nodes - k ** L
+    co, ch, nxt = [0], [], 1
+    for v in range(n_nodes):
+        if v < first_leaf:
+            ch.extend(range(nxt, nxt + k))
+            nxt += k
+        co.append(len(ch))
+    ndesc = np.stack([d0[v % len(d0)] for v in range(n_nodes)])
+    wid = np.array([v - first_leaf if v >= first_leaf else 0 for v in range(n_nodes)], np.uint32)
+    wt = [0.0 if v % 7 == 3 else 0.5 + 0.25 * (v % 5) for v in range(n_nodes)]
+    ow, on = oracle.bow_transform(d1, co, ch, ndesc, wid, L, 2)
+    v, fv = {}, {}
+    for i in range(len(d1)):
+        w = wt[first_leaf + int(ow[i])]
+        if w > 0:
+            v[int(ow[i])] = v.get(int(ow[i]), 0.0) + w
+            fv.setdefault(int(on[i]), []).append(i)
+    tot = 0.0
+    for kk in sorted(v):
+        tot += abs(v[kk])
+    n_bv = take("i")
+    got_bv = dict(take("id") for _ in range(n_bv))
+    assert got_bv == {kk: v[kk] / tot for kk in sorted(v)} and n_bv > 3
+    n_fv = take("i")
+    got_fv = {}
+    for _ in range(n_fv):
+        node, cnt = take("ii")
+        got_fv[node] = [take("i") for _ in range(cnt)]
+    assert got_fv == fv
     assert take("I") == oracle.predict_scale(1.0, 3.0, 1.2, 8)
     s3 = 1.0 * 1.2 * 1.2 * 1.2
     assert take("d") == s3 * s3

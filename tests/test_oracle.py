@@ -398,3 +398,58 @@ def test_match_bow_vs_literal(oracle):
             assert got == want
             for i, j in got.items():
                 assert md[i] == ham(to[i], frm[j])
+
+
+def test_bow_transform_vs_literal(oracle):
+    """oo_bow_transform against a literal transcription of TemplatedVocabulary::transform (single feature),
+    TemplatedVocabulary.h:1218-1259, on ragged random trees with tied sibling descriptors."""
+    rng = np.random.default_rng(8)
+    ham = lambda a, b: int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+    for trial in range(4):
+        k, L = int(rng.integers(2, 7)), int(rng.integers(1, 5))
+        kids = [[]]
+        frontier = [0]
+        for lvl in range(1, L + 1):
+            nxt = []
+            for v in frontier:
+                if lvl > 1 and rng.random() < 0.2:
+                    continue
+                for _ in range(int(rng.integers(1, k + 1))):
+                    kids.append([])
+                    kids[v].append(len(kids) - 1)
+                    nxt.append(len(kids) - 1)
+            frontier = nxt
+        n = len(kids)
+        for v in range(n):
+            rng.shuffle(kids[v])
+        nd = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        for v in range(n):
+            if len(kids[v]) >= 2:
+                nd[kids[v][-1]] = nd[kids[v][0]]
+        co, ch = [0], []
+        for v in range(n):
+            ch.extend(kids[v])
+            co.append(len(ch))
+        wid = np.arange(n, dtype=np.uint32) * 3 + 1
+        desc = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+        desc[:100] = nd[rng.integers(0, n, 100)]
+        for levelsup in (0, 1, 3, 7):
+            ow, on = oracle.bow_transform(desc, co, ch, nd, wid, L, levelsup)
+            for i in range(len(desc)):
+                nid_level = L - levelsup
+                nid = 0
+                final_id, current_level = 0, 0
+                while True:
+                    current_level += 1
+                    nodes = kids[final_id]
+                    final_id = nodes[0]
+                    best_d = float(ham(desc[i], nd[final_id]))
+                    for idn in nodes[1:]:
+                        d = float(ham(desc[i], nd[idn]))
+                        if d < best_d:
+                            best_d, final_id = d, idn
+                    if current_level == nid_level:
+                        nid = final_id
+                    if not kids[final_id]:
+                        break
+                assert ow[i] == wid[final_id] and on[i] == nid
