@@ -225,6 +225,17 @@ int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_ro
 int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to, const float *angle_from,
                            int32_t n_from, int32_t *match, int32_t *n_discarded);
 
+/* replaces: MapPoint::ComputeDistinctiveDescriptor (map/map_point.cpp:135-171) for a batch of map points.
+ * The observed descriptors of point p are rows offsets[p] .. offsets[p+1] of desc (the order in which
+ * Observation::AppendDescriptorsToList appended them).  best_index[p] = position inside the group of the
+ * descriptor with the smallest median distance to the group (median = element (size_t)(0.5*(N-1)) of the
+ * sorted row, first row on ties), or -1 for an empty group (the reference leaves such a point untouched).
+ * A group may hold at most 65535 descriptors. */
+int orbgpu_distinctive_descriptor(orbgpu_ctx *ctx, const uint8_t *desc, const int32_t *offsets, int32_t n_points,
+                                  int32_t *best_index);
+int orbgpu_distinctive_descriptor_device(orbgpu_ctx *ctx, const uint8_t *d_desc, const int32_t *d_offsets,
+                                         int32_t n_points, int32_t *d_best_index);
+
 /* ---- vocabulary (bag of words) ------------------------------------------------------------------ */
 /* replaces: the per-feature tree descent of DBoW2Handler::Precompute (features/handlers/DBoW2/
  * dbo_w2_handler.cpp:74-93) = TemplatedVocabulary<FORB>::transform(feature, word_id, weight, nid, levelsup)

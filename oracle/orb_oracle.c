@@ -972,6 +972,39 @@ int oo_snn_match(const oo_match_args *a, int32_t *match_from, uint32_t *match_di
   return nmatches;
 }
 
+static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }
+
+void oo_distinctive_descriptor(const uint8_t *desc, const int32_t *offsets, int n_points, int32_t *best) {
+  for (int p = 0; p < n_points; p++) {
+    const int N = offsets[p + 1] - offsets[p];
+    best[p] = -1;
+    if (N == 0) continue; /* :146-148 */
+    const uint8_t *d = desc + (size_t)offsets[p] * 32;
+    int *distances = (int *)malloc(sizeof(int) * (size_t)N * (size_t)N);
+    for (int i = 0; i < N; i++) {
+      distances[i * N + i] = 0;
+      for (int j = i + 1; j < N; j++) {
+        distances[i * N + j] = (int)oo_hamming256(d + (size_t)i * 32, d + (size_t)j * 32);
+        distances[j * N + i] = distances[i * N + j];
+      }
+    }
+    int best_median = INT_MAX, best_idx = 0;
+    int *dists = (int *)malloc(sizeof(int) * (size_t)N);
+    for (int i = 0; i < N; i++) {
+      memcpy(dists, distances + (size_t)i * N, sizeof(int) * (size_t)N);
+      qsort(dists, (size_t)N, sizeof(int), cmp_int);
+      const int median = dists[(size_t)(0.5 * (N - 1))]; /* :160 */
+      if (median < best_median) {
+        best_median = median;
+        best_idx = i;
+      }
+    }
+    best[p] = best_idx;
+    free(dists);
+    free(distances);
+  }
+}
+
 void oo_bow_transform(const uint8_t *desc, int n, const int32_t *child_off, const uint32_t *children,
                       const uint8_t *node_desc, const uint32_t *word_id, int L, int levelsup, uint32_t *out_word,
                       uint32_t *out_node) {

@@ -150,6 +150,12 @@ int oo_match_area(const oo_keypoint *kp_to, const uint8_t *desc_to, int n_to, co
                   const uint8_t *desc_from, int n_from, size_t window, unsigned threshold, double ratio,
                   int32_t *match_from, uint32_t *match_dist);
 
+/* MapPoint::ComputeDistinctiveDescriptor (map/map_point.cpp:135-171) for a batch of map points: the descriptors
+ * of point p are rows offsets[p] .. offsets[p+1] of desc.  best[p] = index (inside the group) of the descriptor
+ * whose sorted distance row has the smallest element at position (size_t)(0.5 * (N - 1)); the first such row
+ * wins (strict <, :162); -1 for an empty group (:146-148 leaves the point untouched). */
+void oo_distinctive_descriptor(const uint8_t *desc, const int32_t *offsets, int n_points, int32_t *best);
+
 /* TemplatedVocabulary<FORB>::transform for one feature (DBoW2/DBoW2/TemplatedVocabulary.h:1218-1259) with
  * FORB::distance (DBoW2/DBoW2/FORB.cpp:81-101), for every row of desc.  The tree is given flat: the children of
  * node v are children[child_off[v] .. child_off[v+1]) in the order of Node::children (a leaf has none), node 0 is

@@ -258,6 +258,14 @@ def match_area(kp_to, desc_to, kp_from, desc_from, window=100, threshold=50, rat
     return mf[:len(kp_to)], md[:len(kp_to)]
 
 
+def distinctive_descriptor(desc, offsets):
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    best = np.zeros(max(len(offsets) - 1, 1), np.int32)
+    lib().oo_distinctive_descriptor(_p(desc), _p(offsets), len(offsets) - 1, _p(best))
+    return best[:len(offsets) - 1]
+
+
 def bow_transform(desc, child_off, children, node_desc, word_id, L, levelsup=4):
     desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
     child_off = np.ascontiguousarray(child_off, np.int32)

@@ -55,7 +55,7 @@ EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_g
            "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_window",
            "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
            "orbgpu_match_allpairs_device", "orbgpu_vocab_create", "orbgpu_vocab_destroy", "orbgpu_bow_transform",
-           "orbgpu_bow_transform_device",
+           "orbgpu_bow_transform_device", "orbgpu_distinctive_descriptor", "orbgpu_distinctive_descriptor_device",
            "orbgpu_rotation_filter", "orbgpu_stage_times",
            "orbgpu_popcount_peak"]
 
@@ -91,6 +91,8 @@ def load():
         "orbgpu_match_groups": (i32, [vp, C.POINTER(GroupArgs), vp, vp]),
         "orbgpu_match_groups_device": (i32, [vp, C.POINTER(GroupArgs), i32, vp, vp]),
         "orbgpu_match_allpairs_device": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, u32, dbl, i32, vp, vp]),
+        "orbgpu_distinctive_descriptor": (i32, [vp, vp, vp, i32, vp]),
+        "orbgpu_distinctive_descriptor_device": (i32, [vp, vp, vp, i32, vp]),
         "orbgpu_vocab_create": (i32, [vp, i32, vp, vp, vp, vp, i32, C.POINTER(vp)]),
         "orbgpu_vocab_destroy": (None, [vp]),
         "orbgpu_bow_transform": (i32, [vp, vp, vp, i32, i32, vp, vp]),

@@ -805,6 +805,52 @@ int orbgpu_match_groups(orbgpu_ctx *ctx, const orbgpu_group_args *a, int32_t *fr
   return ORBGPU_OK;
 }
 
+int orbgpu_distinctive_descriptor_device(orbgpu_ctx *ctx, const uint8_t *d_desc, const int32_t *d_offsets, int32_t n_points,
+                                         int32_t *d_best_index) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (n_points < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (n_points == 0) return ORBGPU_OK;
+  if (!d_offsets || !d_best_index) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  launch_distinctive(ctx, d_desc, d_offsets, n_points, d_best_index);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
+int orbgpu_distinctive_descriptor(orbgpu_ctx *ctx, const uint8_t *desc, const int32_t *offsets, int32_t n_points,
+                                  int32_t *best_index) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  if (n_points < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (n_points == 0) return ORBGPU_OK;
+  if (!offsets || !best_index) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (offsets[0] != 0) return fail(ctx, ORBGPU_E_INVALID, "offsets must start at 0");
+  for (int p = 0; p < n_points; p++) {
+    if (offsets[p + 1] < offsets[p]) return fail(ctx, ORBGPU_E_INVALID, "offsets must be non-decreasing");
+    if (offsets[p + 1] - offsets[p] > 65535) return fail(ctx, ORBGPU_E_CAPACITY, "more than 65535 descriptors in one group");
+  }
+  const size_t total = (size_t)offsets[n_points];
+  if (total > 0 && !desc) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  Staging st{ctx};
+  uint8_t *d_desc;
+  int32_t *d_off, *d_best;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = st.reserve(pad256(total * 32) + pad256(((size_t)n_points + 1) * 4) + pad256((size_t)n_points * 4) + 1024);
+    if (rc) return rc;
+    d_desc = st.put(desc, total * 32);
+    d_off = st.put(offsets, (size_t)n_points + 1);
+    d_best = st.put<int32_t>(nullptr, (size_t)n_points);
+  }
+  int rc = orbgpu_distinctive_descriptor_device(ctx, d_desc, d_off, n_points, d_best);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(hipMemcpyAsync(best_index, d_best, (size_t)n_points * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ORBGPU_OK;
+}
+
 int orbgpu_vocab_create(orbgpu_ctx *ctx, int32_t n_nodes, const int32_t *child_off, const uint32_t *children,
                         const uint8_t *node_desc, const uint32_t *word_id, int32_t levels, orbgpu_vocab **out) {
   if (!ctx) return ORBGPU_E_INVALID;

@@ -572,6 +572,43 @@ __global__ __launch_bounds__(256) void k_bow_transform(const uint8_t *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// MapPoint::ComputeDistinctiveDescriptor (map/map_point.cpp:135-171), batched: one wave per map point, lane = row
+// of the distance matrix (rows beyond 64 in further passes).  The element at position (N-1)/2 of the sorted row is
+// the smallest value m with #{j : d(i,j) <= m} >= (N-1)/2 + 1; distances are 0..256, so 9 bisection steps over m find
+// it, each re-evaluating the row against the wave-uniform (scalar-loaded) descriptors of the group.  The winner is
+// the minimum of (median << 16 | row): smallest median, first row on ties (strict <, :162).
+__global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__ desc, const int *__restrict__ offsets,
+                                                     int n_points, int *__restrict__ best) {
+  const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int lane = threadIdx.x & 63;
+  if (p >= n_points) return;
+  const int o0 = offsets[p], N = offsets[p + 1] - o0;
+  if (N <= 0) {
+    if (lane == 0) best[p] = -1;
+    return;
+  }
+  const uint4 *gd = reinterpret_cast<const uint4 *>(desc) + 2 * (size_t)o0;
+  const int need = ((N - 1) >> 1) + 1;  // (size_t)(0.5 * (N - 1)) + 1 elements must be <= the median
+  unsigned key = 0xffffffffu;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    const uint4 t0 = gd[2 * (size_t)min(i, N - 1)], t1 = gd[2 * (size_t)min(i, N - 1) + 1];
+    const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    int lo = 0, hi = 256;  // invariant: count(<= hi) >= need; answer in [lo, hi]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      int cnt = 0;
+      for (int j = 0; j < N; j++) cnt += hamming8(t, gd[2 * (size_t)j], gd[2 * (size_t)j + 1]) <= (unsigned)mid ? 1 : 0;
+      if (cnt >= need) hi = mid; else lo = mid + 1;
+    }
+    if (i < N) key = min(key, ((unsigned)lo << 16) | (unsigned)i);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) key = min(key, (unsigned)__shfl_xor((int)key, o));
+  if (lane == 0) best[p] = (int)(key & 0xffffu);
+}
+
+// ------------------------------------------------------------------------------------------------
 // All-pairs keyframe matching: 'to' = keyframe r of the row set, 'from' = keyframe c of the column set,
 // SNNMatcher::MatchWithIterators semantics with no candidate restriction (every 'from' in index order), then the
 // optional rotation histogram.  One workgroup owns one (r, c) pair from the scan to the match count, so nothing but
@@ -809,6 +846,11 @@ void launch_bow_transform(const orbgpu_ctx *c, const orbgpu_vocab *v, const uint
   if (n == 0) return;
   hipLaunchKernelGGL(k_bow_transform, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_desc, n, v->d_child_off,
                      v->d_children, v->d_node_desc, v->d_word_id, v->levels - levelsup, v->n_nodes, d_word, d_node);
+}
+
+void launch_distinctive(const orbgpu_ctx *c, const uint8_t *d_desc, const int *d_offsets, int n_points, int *d_best) {
+  if (n_points == 0) return;
+  hipLaunchKernelGGL(k_distinctive, dim3((n_points + 3) / 4), dim3(256), 0, c->stream, d_desc, d_offsets, n_points, d_best);
 }
 
 size_t allpairs_lds_bytes(int capacity) { return (size_t)capacity * 16; }

@@ -164,6 +164,7 @@ void launch_match_groups(const orbgpu_ctx *c, const orbgpu_group_args &a, int n_
                          void *scratch);
 void launch_bow_transform(const orbgpu_ctx *c, const orbgpu_vocab *v, const uint8_t *d_desc, int n, int levelsup,
                           unsigned *d_word, unsigned *d_node);
+void launch_distinctive(const orbgpu_ctx *c, const uint8_t *d_desc, const int *d_offsets, int n_points, int *d_best);
 size_t allpairs_lds_bytes(int capacity);
 void launch_match_allpairs(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
                            const int *d_n_rows, int n_rows, const orbgpu_keypoint *d_kp_cols, const uint8_t *d_desc_cols,

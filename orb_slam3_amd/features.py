@@ -314,3 +314,18 @@ class OrientationValidator:
             if m[i] < 0:
                 del inout_matches_12[i]
         return nd.value
+
+
+def ComputeDistinctiveDescriptors(feature_extractor, descriptor_groups):
+    """MapPoint::ComputeDistinctiveDescriptor (map/map_point.cpp:135-171) for many map points in one call.
+    descriptor_groups: one (N_p x 32) uint8 array per map point (its observations' descriptors in
+    AppendDescriptorsToList order).  Returns per point the index of the chosen descriptor, or -1 if it has none."""
+    groups = [np.ascontiguousarray(g, np.uint8).reshape(-1, 32) for g in descriptor_groups]
+    offsets = np.zeros(len(groups) + 1, np.int32)
+    for p, g in enumerate(groups):
+        offsets[p + 1] = offsets[p] + len(g)
+    desc = np.concatenate(groups) if groups and offsets[-1] else np.zeros((0, 32), np.uint8)
+    best = np.full(max(len(groups), 1), -1, np.int32)
+    feature_extractor._check(feature_extractor._lib.orbgpu_distinctive_descriptor(
+        feature_extractor.handle, _lib.ptr(desc), _lib.ptr(offsets), len(groups), _lib.ptr(best)))
+    return best[:len(groups)]

@@ -11,6 +11,7 @@
 #include "hip_orb_feature_extractor.h"
 #include "hip_snn_matcher.h"
 #include "hip_bow_vocabulary.h"
+#include "hip_map_point.h"
 
 using namespace orb_slam3;
 
@@ -108,6 +109,16 @@ int main(int argc, char ** argv) {
   TestFeatureVector tfv;
   voc.transform(f1.descriptors.data(), f1.Size(), bv, tfv, 2);
 
+  // MapPoint::ComputeDistinctiveDescriptor, map_point.cpp:135-171: "map point" g is observed by the descriptors
+  // g, g+7, g+14, ... of frame 0 (g < 7; sizes differ by one, some even, some odd)
+  std::vector<std::vector<features::DescriptorType>> groups(8);   // the last group stays empty
+  for (size_t j = 0; j < f0.Size(); ++j) {
+    features::DescriptorType d;
+    std::memcpy(d.d, f0.descriptors.data() + 32 * j, 32);
+    groups[j % 7].push_back(d);
+  }
+  const std::vector<int32_t> distinctive = map::HipComputeDistinctiveDescriptors(hip->context(), groups);
+
   std::ofstream o(argv[6], std::ios::binary);
   for (const features::Features * f : {&f0, &f1}) {
     put(o, (int32_t)f->Size());
@@ -124,6 +135,8 @@ int main(int argc, char ** argv) {
   for (const auto & kv : bv) { put(o, (int32_t)kv.first); put(o, kv.second); }
   put(o, (int32_t)tfv.size());
   for (const auto & kv : tfv) { put(o, (int32_t)kv.first); put(o, (int32_t)kv.second.size()); for (unsigned i : kv.second) put(o, (int32_t)i); }
+  put(o, (int32_t)distinctive.size());
+  for (int32_t b : distinctive) put(o, b);
   // scalar helpers
   put(o, (uint32_t)fe->PredictScale(1.0, 3.0)); put(o, fe->GetAcceptableSquareError(3));
   features::DescriptorType a, b; std::memcpy(a.d, f0.descriptors.data(), 32); std::memcpy(b.d, f0.descriptors.data() + 32, 32);

@@ -116,6 +116,11 @@ def test_cpp_adapter_end_to_end(oracle, tmp_path):
         node, cnt = take("ii")
         got_fv[node] = [take("i") for _ in range(cnt)]
     assert got_fv == fv
+    n_groups = take("i")
+    got_best = [take("i") for _ in range(n_groups)]
+    grp = [d0[g::7] for g in range(7)] + [np.zeros((0, 32), np.uint8)]
+    off = np.cumsum([0] + [len(g) for g in grp]).astype(np.int32)
+    assert got_best == oracle.distinctive_descriptor(np.concatenate(grp), off).tolist() and got_best[-1] == -1
     assert take("I") == oracle.predict_scale(1.0, 3.0, 1.2, 8)
     s3 = 1.0 * 1.2 * 1.2 * 1.2
     assert take("d") == s3 * s3

@@ -223,3 +223,25 @@ def test_bow_group_errors(fe):
     a = _lib.GroupArgs(_lib.ptr(d), 4, _lib.ptr(d), 4, 0, None, None, None, None, 50, 0.9)   # no shared node: no matches
     assert lib.orbgpu_match_groups(fe.handle, C.byref(a), _lib.ptr(idx), _lib.ptr(dist)) == 0
     assert (idx == -1).all()
+
+
+def test_distinctive_descriptor_parity(oracle, fe):
+    """orbgpu_distinctive_descriptor (MapPoint::ComputeDistinctiveDescriptor, batched) against the oracle."""
+    from orb_slam3_amd.features import ComputeDistinctiveDescriptors
+    rng = np.random.default_rng(14)
+    sizes = [0, 1, 2, 3, 4, 5, 8, 13, 33, 64, 65, 127, 200] + rng.integers(1, 40, 3000).tolist()
+    groups = []
+    for n in sizes:
+        centre = rng.integers(0, 256, 32, dtype=np.uint8)
+        g = np.repeat(centre[None], n, 0)
+        flips = rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8) & rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        g = g ^ flips                      # observations of one point: noisy copies of a centre
+        if n > 3 and n % 3 == 0:
+            g[2] = g[0]                    # ties
+        groups.append(g)
+    off = np.cumsum([0] + [len(g) for g in groups]).astype(np.int32)
+    want = oracle.distinctive_descriptor(np.concatenate(groups), off)
+    got = ComputeDistinctiveDescriptors(fe, groups)
+    assert np.array_equal(got, want)
+    assert len(ComputeDistinctiveDescriptors(fe, [])) == 0
+    assert ComputeDistinctiveDescriptors(fe, [np.zeros((0, 32), np.uint8)])[0] == -1

@@ -453,3 +453,26 @@ def test_bow_transform_vs_literal(oracle):
                     if not kids[final_id]:
                         break
                 assert ow[i] == wid[final_id] and on[i] == nid
+
+
+def test_distinctive_descriptor_vs_literal(oracle):
+    """oo_distinctive_descriptor against a transcription of map_point.cpp:135-171 (sort + element 0.5*(N-1))."""
+    rng = np.random.default_rng(4)
+    groups = [rng.integers(0, 256, (n, 32), dtype=np.uint8) for n in (0, 1, 2, 3, 4, 7, 10, 33, 64, 65, 130)]
+    groups[5][3] = groups[5][0]          # duplicates: equal medians, first row wins
+    groups[6][:] = groups[6][0]          # all identical
+    off = np.cumsum([0] + [len(g) for g in groups]).astype(np.int32)
+    got = oracle.distinctive_descriptor(np.concatenate(groups), off)
+    for p, g in enumerate(groups):
+        N = len(g)
+        if N == 0:
+            assert got[p] == -1
+            continue
+        bits = np.unpackbits(g, axis=1).astype(np.int32)
+        dist = (bits[:, None, :] != bits[None, :, :]).sum(-1)
+        best_median, best_idx = 2 ** 31 - 1, 0
+        for i in range(N):
+            median = sorted(dist[i].tolist())[int(0.5 * (N - 1))]
+            if median < best_median:
+                best_median, best_idx = median, i
+        assert got[p] == best_idx
