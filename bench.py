@@ -43,12 +43,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 control flow on a one-GPU box: ORB_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # uses gloo (RCCL wants one GPU per rank); never set by the driver
+    rehearsal = os.environ.get("ORB_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from orb_slam3_amd import _lib, synth
     from orb_slam3_amd.features import ORBFeatureExtractor
