@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     const int ry = ty + 8 * part;
     const int y = y0 + ry, x = x0 + 4 * tx;
     unsigned mask = 0;  // bit p: pixel x+p may be a corner
-    if (y >= 3 && y <= L.h - 4) {
+    if (y >= ORB_EDGE && y <= L.h - ORB_EDGE - 1) {  // only the cells' detection rectangles are ever read
       // 12-byte windows (columns x-4 .. x+7) of the 7 rows y-3 .. y+3
       unsigned w[7][3];
 #pragma unroll
@@ -170,10 +170,10 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
         const unsigned c1 = (dark_lim.y < v.y) | (bright_lim.y < mn_of_max.y);
         mask |= (c0 | (c1 << 1)) << (2 * pr);
       }
-      // the scan region of a level is [3, w-4]
+      // the cells' detection rectangles tile [19, w-20] x [19, h-20] (k_cell_detect); nothing outside is read
 #pragma unroll
       for (int p = 0; p < 4; p++)
-        if (x + p < 3 || x + p > L.w - 4) mask &= ~(1u << p);
+        if (x + p < ORB_EDGE || x + p > L.w - ORB_EDGE - 1) mask &= ~(1u << p);
     }
     mask16 |= mask << (4 * part);
   }
