@@ -84,35 +84,31 @@ constexpr int PR = 19;              // patch radius staged for the descriptor (t
 constexpr int PW = 2 * PR + 1;      // 39 rows
 constexpr int PDW = 11;             // aligned dwords per staged row: 39 bytes + up to 3 bytes of misalignment
 constexpr int PPITCH = PDW * 4;     // 44
-constexpr int KPB = 8;              // keypoints (waves) per workgroup
+constexpr int KPB = 8;              // waves per workgroup
+constexpr int KPW = 2;              // keypoints per wave, processed side by side so that twice as many loads are in flight
+constexpr int KPG = KPB * KPW;      // keypoint slots per workgroup
+constexpr int PATCH_DW = PW * PDW + 11;
 
-// blockDim = 512 = 8 waves = 8 keypoint slots; 1-D grid over (slot group, frame) in XCD order.
-// Everything that depends only on the slot is forced wave-uniform (readfirstlane) so it runs on the scalar ALU.
-__global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
-                                                         DeviceGeom g, const short2 *__restrict__ kp_xy,
-                                                         const int *__restrict__ kp_count,
-                                                         orbgpu_keypoint *__restrict__ out_kp,
-                                                         uint8_t *__restrict__ out_desc, int capacity,
-                                                         int *__restrict__ out_n, int n_frames) {
-  __shared__ unsigned patch[KPB][PW * PDW + 16];
-  __shared__ float s_angle[KPB];
-  __shared__ float s_cs[KPB][2];
+// blockDim = 64 * KPB; 1-D grid over (slot group, frame) in XCD order.  The kernel is latency-bound (keypoint -> patch
+// -> orientation -> sin/cos -> taps is a chain of dependent memory round trips), so it is organised for loads in
+// flight, not for instruction count: a wave owns two keypoints, the blurred patches go straight from global memory
+// to LDS (global_load_lds: no staging registers, 8 waves per SIMD), and everything that depends only on the slot is
+// forced wave-uniform (readfirstlane) so it runs on the scalar ALU.
+__global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__restrict__ pyr,
+                                                              const uint8_t *__restrict__ blur, DeviceGeom g,
+                                                              const short2 *__restrict__ kp_xy,
+                                                              const int *__restrict__ kp_count,
+                                                              orbgpu_keypoint *__restrict__ out_kp,
+                                                              uint8_t *__restrict__ out_desc, int capacity,
+                                                              int *__restrict__ out_n, int n_frames) {
+  __shared__ unsigned patch[KPG][PATCH_DW];
+  __shared__ float s_angle[KPG];
+  __shared__ float s_cs[KPG][2];
   __shared__ int s_prefix[ORBGPU_MAX_LEVELS];
   int f, group;
-  if (!xcd_item_frame((g.kps_per_frame + KPB - 1) / KPB, n_frames, group, f)) return;
+  if (!xcd_item_frame((g.kps_per_frame + KPG - 1) / KPG, n_frames, group, f)) return;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  // the lane's 4 test patterns: independent of everything else, so their latency hides behind the whole kernel
-  const float4 *pat = reinterpret_cast<const float4 *>(c_pattern.v);
-  float4 ptn[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) ptn[q] = pat[64 * q + lane];
-  const int slot = group * KPB + wave;
   const int *cnt = kp_count + f * g.levels;
-  const int l = level_of(g.kp_offs, slot);
-  const LevelGeom L = g.lv[l];
-  const int i = slot - L.kp_off;
-  // validity is wave-uniform; invalid waves only take part in the barriers
-  const bool valid = slot < g.kps_per_frame && i < cnt[l];
   // inclusive prefix of the per-level counts, once per workgroup (16 lanes of wave 0); read after the barriers
   if (threadIdx.x < ORBGPU_MAX_LEVELS) {
     int v = (int)threadIdx.x < g.levels ? cnt[threadIdx.x] : 0;
@@ -124,48 +120,75 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
     s_prefix[threadIdx.x] = v;
   }
 
-  int cx = 0, cy = 0;
-  float angle = 0.f;
-  int sh = 0;
-  if (valid) {
-    const short2 xy = kp_xy[(size_t)f * g.kps_per_frame + slot];
-    cx = __builtin_amdgcn_readfirstlane((int)xy.x);
-    cy = __builtin_amdgcn_readfirstlane((int)xy.y);
-    const size_t base = (size_t)f * g.frame_bytes + L.off;
-    // ---- issue the blurred-patch loads first (39 rows x 11 aligned dwords; 5 rows = 55 lanes per step), they land
-    //      during the orientation.  LDS index of (row 5k + lane/11, dword lane%11) is simply 55k + lane.
-    const int xb = (cx - PR) & ~3;
-    sh = (cx - PR) - xb;
-    const int psub = lane / PDW, pc4 = 4 * (lane - psub * PDW);
-    const uint8_t *bsrc = blur + base + (size_t)(cy - PR) * L.pitch + xb;
-    const unsigned poff = (unsigned)(psub * L.pitch + pc4);
-    unsigned pv[8];
+  int slot[KPW], lv[KPW], idx[KPW], cx[KPW], cy[KPW], sh[KPW];
+  bool valid[KPW];  // wave-uniform; invalid halves only take part in the barriers
+  unsigned l_off[KPW];
+  int l_pitch[KPW];
+  float angle[KPW];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      pv[k] = 0;
-      if (lane < 5 * PDW && 5 * k + psub < PW) pv[k] = *reinterpret_cast<const unsigned *>(bsrc + (poff + (unsigned)(5 * k * L.pitch)));
-    }
-    // ---- orientation on the unblurred level (IC_Angle): 31 rows x 9 aligned dwords, 7 rows = 63 lanes per step
-    const int xo = (cx - ORB_HALF_PATCH) & ~3;
-    const int osh = (cx - ORB_HALF_PATCH) - xo;
-    const int osub = lane / ODW, oc4 = 4 * (lane - osub * ODW);
-    const uint8_t *osrc = pyr + base + (size_t)(cy - ORB_HALF_PATCH) * L.pitch + xo;
-    const unsigned ooff = (unsigned)(osub * L.pitch + oc4);
-    unsigned ov[5];
-    uint2 ow[5];
+  for (int h = 0; h < KPW; h++) {
+    slot[h] = group * KPG + wave * KPW + h;
+    lv[h] = level_of(g.kp_offs, slot[h]);
+    const LevelGeom &L = g.lv[lv[h]];
+    idx[h] = slot[h] - L.kp_off;
+    l_off[h] = L.off;
+    l_pitch[h] = L.pitch;
+    valid[h] = slot[h] < g.kps_per_frame && idx[h] < cnt[lv[h]];
+    cx[h] = cy[h] = sh[h] = 0;
+    angle[h] = 0.f;
+  }
+  short2 xy[KPW];
+#pragma unroll
+  for (int h = 0; h < KPW; h++) {
+    xy[h] = make_short2(0, 0);
+    if (valid[h]) xy[h] = kp_xy[(size_t)f * g.kps_per_frame + slot[h]];
+  }
+  // ---- blurred patches: 39 rows x 11 aligned dwords, 5 rows = 55 lanes per step, global -> LDS directly.  The LDS
+  //      address of (row 5k + lane/11, dword lane%11) is 55k + lane, which is what the instruction writes (base + 4*lane)
+  const int psub = lane / PDW, pc4 = 4 * (lane - psub * PDW);
+#pragma unroll
+  for (int h = 0; h < KPW; h++) {
+    if (!valid[h]) continue;
+    cx[h] = __builtin_amdgcn_readfirstlane((int)xy[h].x);
+    cy[h] = __builtin_amdgcn_readfirstlane((int)xy[h].y);
+    const int xb = (cx[h] - PR) & ~3;
+    sh[h] = (cx[h] - PR) - xb;
+    const uint8_t *bsrc = blur + (size_t)f * g.frame_bytes + l_off[h] + (size_t)(cy[h] - PR) * l_pitch[h] + xb;
+    const unsigned poff = (unsigned)(psub * l_pitch[h] + pc4);
+    unsigned *P = patch[wave * KPW + h];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (lane < 5 * PDW && 5 * k + psub < PW)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned *>(bsrc + (poff + (unsigned)(5 * k * l_pitch[h]))),
+                                         P + 55 * k, 4, 0, 0);
+  }
+  // ---- orientation on the unblurred level (IC_Angle): 31 rows x 9 aligned dwords, 7 rows = 63 lanes per step
+  const int osub = lane / ODW, oc4 = 4 * (lane - osub * ODW);
+  unsigned ov[KPW][5];
+#pragma unroll
+  for (int h = 0; h < KPW; h++) {
+    const int xo = (cx[h] - ORB_HALF_PATCH) & ~3;
+    const uint8_t *osrc = pyr + (size_t)f * g.frame_bytes + l_off[h] + (size_t)(cy[h] - ORB_HALF_PATCH) * l_pitch[h] + xo;
+    const unsigned ooff = (unsigned)(osub * l_pitch[h] + oc4);
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      ov[k] = 0;
-      ow[k] = c_orient.e[osh * OT_STRIDE + 63 * k + min(lane, 62)];
-      if (lane < 63 && 7 * k + osub < ORB_PATCH) ov[k] = *reinterpret_cast<const unsigned *>(osrc + (ooff + (unsigned)(7 * k * L.pitch)));
+      ov[h][k] = 0;
+      if (valid[h] && lane < 63 && 7 * k + osub < ORB_PATCH)
+        ov[h][k] = *reinterpret_cast<const unsigned *>(osrc + (ooff + (unsigned)(7 * k * l_pitch[h])));
     }
+  }
+#pragma unroll
+  for (int h = 0; h < KPW; h++) {
+    if (!valid[h]) continue;
+    const int osh = (cx[h] - ORB_HALF_PATCH) & 3;
     unsigned a10 = 0, si = 0;
     int m01 = 0;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
       // rows beyond the disc and lane 63 read weight 0 / pixel 0
-      const unsigned rs = __builtin_amdgcn_udot4(ov[k], ow[k].y, 0u, false);
-      a10 = __builtin_amdgcn_udot4(ov[k], ow[k].x, a10, false);
+      const uint2 ow = c_orient.e[osh * OT_STRIDE + 63 * k + min(lane, 62)];
+      const unsigned rs = __builtin_amdgcn_udot4(ov[h][k], ow.y, 0u, false);
+      a10 = __builtin_amdgcn_udot4(ov[h][k], ow.x, a10, false);
       si += rs;
       m01 += (7 * k + osub - ORB_HALF_PATCH) * (int)rs;
     }
@@ -175,17 +198,14 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
       m10 += __shfl_xor(m10, off);
       m01 += __shfl_xor(m01, off);
     }
-    angle = fast_atan2_deg((float)m01, (float)m10);
-    if (lane == 0) s_angle[wave] = angle;
-    unsigned *P = patch[wave];
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (lane < 5 * PDW) P[55 * k + lane] = pv[k];   // rows 39.. of the last step land in the 16-dword pad
+    angle[h] = fast_atan2_deg((float)m01, (float)m10);
+    if (lane == 0) s_angle[wave * KPW + h] = angle[h];
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the direct-to-LDS patch loads have landed
   __syncthreads();
-  // ---- cos/sin for the whole workgroup by 8 lanes of wave 0: float(angle_deg) * (double)(pi/180) -> float,
+  // ---- cos/sin for the whole workgroup by 16 lanes of wave 0: float(angle_deg) * (double)(pi/180) -> float,
   //      cos/sin evaluated in double and rounded to float
-  if (threadIdx.x < KPB) {
+  if (threadIdx.x < KPG) {
     const double factorPI = 3.14159265358979323846 / 180.;
     const float ang = (float)((double)s_angle[threadIdx.x] * factorPI);
     double sn, cs;
@@ -196,38 +216,49 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
   __syncthreads();
   const int total = s_prefix[ORBGPU_MAX_LEVELS - 1];
   if (group == 0 && threadIdx.x == 0) out_n[f] = total;
-  if (!valid || total > capacity) return;
-  const int pos = total - 1 - ((l ? s_prefix[l - 1] : 0) + i);  // reversed packing, SURVEY App. B.4
-  const float a = s_cs[wave][0], b = s_cs[wave][1];
-  // ---- rotated BRIEF: taps = cvRound(x*b + y*a), cvRound(x*a - y*b), float32 without FMA
-  const uint8_t *P8 = reinterpret_cast<const uint8_t *>(patch[wave]) + PR * PPITCH + PR + sh;  // the keypoint's byte
-  unsigned long long bits[4];
+  if (total > capacity || !(valid[0] || valid[1])) return;
+  // the lane's 4 test patterns (pattern_, 16 bytes each), shared by the wave's two keypoints
+  const float4 *pat = reinterpret_cast<const float4 *>(c_pattern.v);
+  float4 ptn[4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const float4 pt = ptn[q];
-    const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
-    const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
-    const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
-    const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
-    const int t0 = P8[r0 * PPITCH + c0];
-    const int t1 = P8[r1 * PPITCH + c1];
-    bits[q] = __ballot(t0 < t1);  // bit k of byte i = test 8i + k: ballot order is the descriptor's byte order
-  }
-  if (lane == 0) {
-    unsigned long long *d = reinterpret_cast<unsigned long long *>(out_desc + ((size_t)f * capacity + pos) * 32);
-    d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
-    orbgpu_keypoint k;
-    k.x = (double)cx;
-    k.y = (double)cy;
-    if (l != 0) {  // keypoint->pt *= (float)scale_factors_[level], orb_feature_extractor.cpp:568-577
-      k.x *= (double)L.scale_f;
-      k.y *= (double)L.scale_f;
+  for (int q = 0; q < 4; q++) ptn[q] = pat[64 * q + lane];
+#pragma unroll
+  for (int h = 0; h < KPW; h++) {
+    if (!valid[h]) continue;
+    const int l = lv[h];
+    const int pos = total - 1 - ((l ? s_prefix[l - 1] : 0) + idx[h]);  // reversed packing, SURVEY App. B.4
+    const float a = s_cs[wave * KPW + h][0], b = s_cs[wave * KPW + h][1];
+    // ---- rotated BRIEF: taps = cvRound(x*b + y*a), cvRound(x*a - y*b), float32 without FMA
+    const uint8_t *P8 = reinterpret_cast<const uint8_t *>(patch[wave * KPW + h]) + PR * PPITCH + PR + sh[h];
+    unsigned long long bits[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 pt = ptn[q];
+      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+      const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+      const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+      const int t0 = P8[r0 * PPITCH + c0];
+      const int t1 = P8[r1 * PPITCH + c1];
+      bits[q] = __ballot(t0 < t1);  // bit k of byte i = test 8i + k: ballot order is the descriptor's byte order
     }
-    k.angle = angle;
-    k.size = L.kp_size;
-    k.level = l;
-    k.reserved = 0;
-    out_kp[(size_t)f * capacity + pos] = k;
+    if (lane == 0) {
+      unsigned long long *d = reinterpret_cast<unsigned long long *>(out_desc + ((size_t)f * capacity + pos) * 32);
+      d[0] = bits[0]; d[1] = bits[1]; d[2] = bits[2]; d[3] = bits[3];
+      const LevelGeom &L = g.lv[l];
+      orbgpu_keypoint k;
+      k.x = (double)cx[h];
+      k.y = (double)cy[h];
+      if (l != 0) {  // keypoint->pt *= (float)scale_factors_[level], orb_feature_extractor.cpp:568-577
+        k.x *= (double)L.scale_f;
+        k.y *= (double)L.scale_f;
+      }
+      k.angle = angle[h];
+      k.size = L.kp_size;
+      k.level = l;
+      k.reserved = 0;
+      out_kp[(size_t)f * capacity + pos] = k;
+    }
   }
 }
 
@@ -235,7 +266,7 @@ __global__ __launch_bounds__(512) void k_orient_describe(const uint8_t *__restri
 
 void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                             int *d_n_out) {
-  dim3 grid((c->geom.kps_per_frame + KPB - 1) / KPB * xcd_frames(n_frames));
+  dim3 grid((c->geom.kps_per_frame + KPG - 1) / KPG * xcd_frames(n_frames));
   hipLaunchKernelGGL(k_orient_describe, grid, dim3(64 * KPB), 0, c->stream, c->d_pyr, c->d_blur, c->geom, c->d_kp_xy,
                      c->d_kp_count, d_kp, d_desc, capacity, d_n_out, n_frames);
 }
