@@ -286,15 +286,24 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   HIP_TRY(hipEventRecord(ev[2], ctx->stream));
   launch_cell_detect(ctx, n_frames);
   HIP_TRY(hipEventRecord(ev[3], ctx->stream));
+  // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
+  // dependent rounds in 8 x n_frames workgroups and leaves most of the chip idle
+  // (enqueued after the quadtree so that the quadtree's workgroups are placed first and the blur fills the rest)
+  if (!ctx->host_quadtree) {
+    if (launch_quadtree(ctx, n_frames, budget) != 0)
+      return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
+    HIP_TRY(hipEventRecord(ev[4], ctx->stream));
+  }
+  HIP_TRY(hipStreamWaitEvent(ctx->stream_blur, ev[3], 0));
+  HIP_TRY(hipEventRecord(ev[7], ctx->stream_blur));
+  launch_blur(ctx, n_frames, ctx->stream_blur);
+  HIP_TRY(hipEventRecord(ev[8], ctx->stream_blur));
   if (ctx->host_quadtree) {
     int rc = host_quadtree_stage(ctx, n_frames, budget);
     if (rc) return rc;
-  } else {
-    if (launch_quadtree(ctx, n_frames, budget) != 0)
-      return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
+    HIP_TRY(hipEventRecord(ev[4], ctx->stream));
   }
-  HIP_TRY(hipEventRecord(ev[4], ctx->stream));
-  launch_blur(ctx, n_frames);
+  HIP_TRY(hipStreamWaitEvent(ctx->stream, ev[8], 0));
   HIP_TRY(hipEventRecord(ev[5], ctx->stream));
   launch_orient_describe(ctx, n_frames, d_kp, d_desc, capacity, d_n_out);
   HIP_TRY(hipEventRecord(ev[6], ctx->stream));
@@ -317,7 +326,9 @@ int finish_pipeline(orbgpu_ctx *ctx) {
     float acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int k = 1; k <= n; k++) {
       hipEvent_t *ev = ctx->ev[(ctx->ev_head - k + ORBGPU_EV_SETS) % ORBGPU_EV_SETS];
-      for (int i = 0; i < 6; i++) acc[i] += elapsed(ev[i], ev[i + 1]);
+      for (int i = 0; i < 4; i++) acc[i] += elapsed(ev[i], ev[i + 1]);
+      acc[4] += elapsed(ev[7], ev[8]);  // blur, on its own stream (overlaps the quadtree stage)
+      acc[5] += elapsed(ev[5], ev[6]);
       acc[6] += elapsed(ev[0], ev[6]);
     }
     for (int i = 0; i < 7; i++) ctx->stage_ms[i] = acc[i] / (float)n;
@@ -399,6 +410,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   auto alloc_all = [&]() -> int {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_blur, hipStreamNonBlocking));
     for (auto &set : ctx->ev)
       for (auto &ev : set) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(dmalloc(&ctx->d_pyr, B * g.frame_bytes + 256));
@@ -458,6 +470,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   for (auto &set : ctx->ev)
     for (auto &ev : set)
       if (ev) (void)hipEventDestroy(ev);
+  if (ctx->stream_blur) (void)hipStreamDestroy(ctx->stream_blur);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -277,7 +277,7 @@ void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level) {
                      c->rs_pitch[level], n_frames);
 }
 
-void launch_blur(const orbgpu_ctx *c, int n_frames) {
+void launch_blur(const orbgpu_ctx *c, int n_frames, hipStream_t stream) {
   dim3 grid(c->geom.ftiles_per_frame * xcd_frames(n_frames));
-  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_blur, c->geom, n_frames);
+  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, stream, c->d_pyr, c->d_blur, c->geom, n_frames);
 }

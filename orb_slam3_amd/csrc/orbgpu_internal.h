@@ -77,6 +77,7 @@ struct orbgpu_ctx {
   int rs_pitch[ORBGPU_MAX_LEVELS]{}, rs_rows[ORBGPU_MAX_LEVELS]{};  // LDS footprint of a resize tile (bytes per row, rows)
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream_blur = nullptr;  // the blur runs beside the (latency-bound) quadtree kernel
   std::mutex mu;
   std::string err;
 
@@ -114,7 +115,8 @@ struct orbgpu_ctx {
   void *d_match_scratch = nullptr;
   size_t match_scratch_bytes = 0;
 
-  hipEvent_t ev[ORBGPU_EV_SETS][7]{};  // stage boundaries of the last ORBGPU_EV_SETS extract calls (ring)
+  hipEvent_t ev[ORBGPU_EV_SETS][9]{};  // stage boundaries of the last ORBGPU_EV_SETS extract calls (ring);
+                                       // [7], [8] bracket the blur on stream_blur
   int ev_head = 0, ev_pending = 0;
   float stage_ms[7]{};
   int last_frames = 0;
@@ -138,7 +140,7 @@ int fail_hip(orbgpu_ctx *ctx, hipError_t e, const char *expr, const char *file, 
 void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level);
 void launch_fast_score(const orbgpu_ctx *c, int n_frames);
 void launch_cell_detect(const orbgpu_ctx *c, int n_frames);
-void launch_blur(const orbgpu_ctx *c, int n_frames);
+void launch_blur(const orbgpu_ctx *c, int n_frames, hipStream_t stream);
 void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                             int *d_n_out);
 void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t frame_stride, int stride, int n_frames);
