@@ -100,3 +100,49 @@ def test_host_quadtree_cross_check(oracle, monkeypatch):
     assert np.array_equal(res[0].keypoints, res[1].keypoints) and np.array_equal(res[0].descriptors, res[1].descriptors)
     okp, odesc = oracle.extract_literal(oracle.params(640, 480), img, 1000)
     _kp_equal(res[1].keypoints, okp)
+
+
+def _scene(kind, seed, h, w):
+    rng = np.random.default_rng(seed)
+    if kind == "checker":          # exact ties everywhere: equal scores, equal node sizes, equal responses
+        yy, xx = np.mgrid[0:h, 0:w]
+        return ((((yy // 9) + (xx // 11)) & 1) * 180 + 30).astype(np.uint8)
+    if kind == "saturated":        # clipped blobs on black: rings full of 0 / 255
+        img = np.zeros((h, w), np.uint8)
+        for _ in range(300):
+            y, x, r = int(rng.integers(0, h)), int(rng.integers(0, w)), int(rng.integers(2, 12))
+            img[max(y - r, 0):y + r, max(x - r, 0):x + r] = 255
+        return img
+    if kind == "gradient":         # smooth ramp + sparse dots: most cells empty even at the low threshold
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = ((yy * 255 // h + xx * 255 // w) // 2).astype(np.uint8)
+        for _ in range(40):
+            img[int(rng.integers(20, h - 20)), int(rng.integers(20, w - 20))] = 255
+        return img
+    return synth.frame(seed, h, w)
+
+
+@pytest.mark.parametrize("w,h,nfeat,scale,levels,fi,fm,kind,seed", [
+    (640, 480, 1000, 1.5, 5, 20, 7, "rich", 41),        # coarse pyramid
+    (640, 480, 1000, 1.1, 12, 20, 7, "rich", 42),       # fine pyramid, 12 levels
+    (640, 480, 500, 1.2, 1, 20, 7, "rich", 43),         # a single level
+    (333, 251, 600, 1.2, 6, 20, 7, "rich", 44),         # odd sizes: unaligned rows, partial tiles everywhere
+    (1001, 517, 2000, 1.3, 7, 30, 10, "rich", 45),      # other FAST thresholds
+    (640, 480, 1000, 1.2, 8, 12, 5, "rich", 46),
+    (640, 480, 1000, 1.2, 8, 20, 7, "checker", 47),
+    (640, 480, 1000, 1.2, 8, 20, 7, "saturated", 48),
+    (640, 480, 1000, 1.2, 8, 20, 7, "gradient", 49),
+    (3840, 2160, 5000, 1.2, 8, 20, 7, "rich", 50),      # BASELINE.json configs[2], 4K
+])
+def test_extract_parameter_sweep(oracle, w, h, nfeat, scale, levels, fi, fm, kind, seed):
+    """other constructor arguments, image sizes and degenerate scenes: keypoints and descriptors against the oracle"""
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    img = _scene(kind, seed, h, w)
+    p = oracle.params(w, h, scale, levels, fi, fm)
+    okp, odesc = oracle.extract_literal(p, img, nfeat)
+    fe = ORBFeatureExtractor(w, h, scale, levels, fi, fm, max_features=nfeat)
+    ft = Features(w, h)
+    assert fe.Extract(img, ft, nfeat) == 0
+    _kp_equal(ft.keypoints, okp)
+    assert np.array_equal(ft.descriptors, odesc)
+    fe.close()
