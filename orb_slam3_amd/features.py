@@ -20,16 +20,59 @@ ORBFE = 0  # FeatureExtractorType::ORBFE, feature_extractor_type.h:9-12
 
 
 class Features:
-    """features::Features (features.h:23-54): descriptors N x 32 u8 + keypoints."""
+    """features::Features (features.h:23-54): descriptors N x 32 u8 + keypoints (+ the per-keypoint geometry the
+    feature-handler factory fills afterwards, factories/feature_handler_factory.cpp:53-60)."""
 
     def __init__(self, width, height):
         self.image_width = float(width)
         self.image_height = float(height)
         self.descriptors = np.zeros((0, 32), np.uint8)
         self.keypoints = np.zeros(0, KP_DTYPE)
+        self.undistorted_keypoints = np.zeros((0, 2), np.float64)
+        self.undistorted_and_unprojected_keypoints = np.zeros((0, 3), np.float64)
 
     def Size(self):
         return len(self.keypoints)
+
+    # -- wire format of operator<< / Features(std::istream &), features.cpp:14-79 (little endian, x86-64):
+    #    image_width, image_height (precision_t = f64); descriptor cols, rows (Eigen::Index = i64); rows x cols bytes;
+    #    per keypoint: level i32, size f64, angle f64, pt 2 x f64; then rows x 2 f64 undistorted and rows x 3 f64
+    #    unprojected points.  The reader consumes `rows` entries of each array, so all of them are written.
+    def Serialize(self):
+        n = self.Size()
+        out = [np.array([self.image_width, self.image_height], "<f8").tobytes(),
+               np.array([self.descriptors.shape[1] if n else 32, n], "<i8").tobytes(),
+               np.ascontiguousarray(self.descriptors, np.uint8).tobytes()]
+        rec = np.zeros(n, np.dtype([("level", "<i4"), ("size", "<f8"), ("angle", "<f8"), ("x", "<f8"), ("y", "<f8")]))
+        rec["level"], rec["size"] = self.keypoints["level"], self.keypoints["size"]
+        rec["angle"], rec["x"], rec["y"] = self.keypoints["angle"], self.keypoints["x"], self.keypoints["y"]
+        out.append(rec.tobytes())
+        for arr, dim in ((self.undistorted_keypoints, 2), (self.undistorted_and_unprojected_keypoints, 3)):
+            a = np.zeros((n, dim), "<f8")
+            a[:len(arr)] = np.asarray(arr, np.float64).reshape(-1, dim)[:n]
+            out.append(a.tobytes())
+        return b"".join(out)
+
+    @classmethod
+    def Deserialize(cls, data):
+        w, h = np.frombuffer(data, "<f8", 2, 0)
+        cols, rows = (int(v) for v in np.frombuffer(data, "<i8", 2, 16))
+        f = cls(w, h)
+        pos = 32
+        f.descriptors = np.frombuffer(data, np.uint8, rows * cols, pos).reshape(rows, cols).copy()
+        pos += rows * cols
+        rec = np.frombuffer(data, np.dtype([("level", "<i4"), ("size", "<f8"), ("angle", "<f8"), ("x", "<f8"), ("y", "<f8")]),
+                            rows, pos)
+        pos += rows * 36
+        f.keypoints = np.zeros(rows, KP_DTYPE)
+        for name in ("level", "size", "angle", "x", "y"):
+            f.keypoints[name] = rec[name]
+        f.undistorted_keypoints = np.frombuffer(data, "<f8", rows * 2, pos).reshape(rows, 2).copy()
+        pos += rows * 16
+        f.undistorted_and_unprojected_keypoints = np.frombuffer(data, "<f8", rows * 3, pos).reshape(rows, 3).copy()
+        pos += rows * 24
+        assert pos == len(data), "trailing bytes"
+        return f
 
 
 class ORBFeatureExtractor:

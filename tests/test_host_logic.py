@@ -115,3 +115,31 @@ def test_interface_mirror_names():
                  "ComputeDistance", "GetScaleFactors", "GetHighThreshold", "GetLowThreshold", "Serialize"):
         assert hasattr(features.ORBFeatureExtractor, name)
     assert hasattr(features.OrientationValidator, "Validate")
+
+
+def test_features_wire_format_round_trip():
+    """Python mirror of operator<< / Features(std::istream &) (features.cpp:14-79), following the reference's own
+    round-trip test (test/features/feature_tests.cpp:54-104): 100 keypoints, 30-byte descriptor rows."""
+    import numpy as np
+    from orb_slam3_amd.features import Features
+    from orb_slam3_amd._lib import KP_DTYPE
+    rng = np.random.default_rng(0)
+    f = Features(100, 200)
+    f.descriptors = rng.integers(0, 255, (100, 30), dtype=np.uint8)
+    f.keypoints = np.zeros(100, KP_DTYPE)
+    f.keypoints["x"], f.keypoints["y"] = rng.uniform(0, 150, 100), rng.uniform(0, 250, 100)
+    f.keypoints["size"], f.keypoints["angle"], f.keypoints["level"] = 1, 23, 5
+    f.undistorted_keypoints = rng.uniform(0, 250, (100, 2))
+    f.undistorted_and_unprojected_keypoints = rng.uniform(0, 30, (100, 3))
+    blob = f.Serialize()
+    assert len(blob) == 16 + 16 + 100 * 30 + 100 * (4 + 8 + 8 + 16) + 100 * 16 + 100 * 24
+    assert np.frombuffer(blob, "<i8", 2, 16).tolist() == [30, 100]      # features_width, features_height
+    g = Features.Deserialize(blob)
+    assert (g.image_width, g.image_height) == (100.0, 200.0)
+    assert np.array_equal(g.descriptors, f.descriptors)
+    for name in ("x", "y", "angle", "size", "level"):
+        assert np.array_equal(g.keypoints[name], f.keypoints[name])
+    assert np.array_equal(g.undistorted_keypoints, f.undistorted_keypoints)
+    assert np.array_equal(g.undistorted_and_unprojected_keypoints, f.undistorted_and_unprojected_keypoints)
+    empty = Features.Deserialize(Features(64, 48).Serialize())
+    assert empty.Size() == 0 and empty.descriptors.shape == (0, 32)
