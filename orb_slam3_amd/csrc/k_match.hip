@@ -431,6 +431,10 @@ __global__ __launch_bounds__(256) void k_link_fused(const orbgpu_keypoint *__res
   const int n_to0 = block_compact_list(n_to, to_list, s_wtot, [&](int i) { return i == 0 || kt[i].level == 0; });
   const int n_from0 = block_compact_list(n_from, from_list, s_wtot, [&](int j) { return kf[j].level == 0; });
   const uint4 *__restrict__ fdesc = reinterpret_cast<const uint4 *>(desc + (size_t)ff * capacity * 32);
+  // the compacted 'from' set is staged through LDS 256 candidates at a time (descriptor + position), so the scan reads
+  // wave-uniform LDS addresses (broadcast) instead of chasing list index -> descriptor through memory per candidate
+  __shared__ uint4 s_fdesc[256][2];
+  __shared__ double2 s_fxy[256];
   for (int s0 = 0; s0 < n_to0; s0 += 256) {
     const int slot = s0 + threadIdx.x;
     const int ti = to_list[min(slot, n_to0 - 1)];
@@ -439,16 +443,27 @@ __global__ __launch_bounds__(256) void k_link_fused(const orbgpu_keypoint *__res
     const uint4 t0 = td[0], t1 = td[1];
     const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
     unsigned best = KEY_NONE, second = KEY_NONE;
-    for (int c = 0; c < n_from0; c++) {
-      const int j = __builtin_amdgcn_readfirstlane(from_list[c]);  // wave-uniform: the loads below are scalar
-      const uint4 a = fdesc[2 * j], b = fdesc[2 * j + 1];
-      const double fx = kf[j].x, fy = kf[j].y;
-      unsigned key = (hamming8(t, a, b) << IDX_BITS) | (unsigned)c;
-      // ListFeaturesInArea(point, window, 0, 0): strict |dx| < r and |dy| < r in double (features.cpp:109-119)
-      const bool ok = fabs(fx - k.x) < window && fabs(fy - k.y) < window;
-      key = ok ? key : KEY_NONE;
-      second = umed3(best, key, second);
-      best = min(best, key);
+    for (int c0 = 0; c0 < n_from0; c0 += 256) {
+      const int nc = min(256, n_from0 - c0);
+      __syncthreads();  // the previous chunk has been consumed
+      if ((int)threadIdx.x < nc) {
+        const int j = from_list[c0 + threadIdx.x];
+        s_fdesc[threadIdx.x][0] = fdesc[2 * j];
+        s_fdesc[threadIdx.x][1] = fdesc[2 * j + 1];
+        s_fxy[threadIdx.x] = make_double2(kf[j].x, kf[j].y);
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int c = 0; c < nc; c++) {
+        const uint4 a = s_fdesc[c][0], b = s_fdesc[c][1];
+        const double2 fxy = s_fxy[c];
+        unsigned key = (hamming8(t, a, b) << IDX_BITS) | (unsigned)(c0 + c);
+        // ListFeaturesInArea(point, window, 0, 0): strict |dx| < r and |dy| < r in double (features.cpp:109-119)
+        const bool ok = fabs(fxy.x - k.x) < window && fabs(fxy.y - k.y) < window;
+        key = ok ? key : KEY_NONE;
+        second = umed3(best, key, second);
+        best = min(best, key);
+      }
     }
     if (slot < n_to0) {
       unsigned d = 0;
@@ -798,7 +813,7 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
                          int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
                          unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,
                          int *d_n_matches) {
-  if (link_fused_lds_bytes(capacity) <= 64 * 1024) {
+  if (link_fused_lds_bytes(capacity) + 13 * 1024 <= 64 * 1024) {  // + the kernel's static staging buffers
     hipLaunchKernelGGL(k_link_fused, dim3(n_pairs), dim3(256), link_fused_lds_bytes(capacity), c->stream, d_kp, d_desc, d_n,
                        capacity, d_to_frame, d_from_frame, (double)window, std::min(threshold, 256u), ratio,
                        check_orientation, d_match, d_dist, d_n_matches);
