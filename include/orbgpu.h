@@ -236,6 +236,34 @@ int orbgpu_distinctive_descriptor(orbgpu_ctx *ctx, const uint8_t *desc, const in
 int orbgpu_distinctive_descriptor_device(orbgpu_ctx *ctx, const uint8_t *d_desc, const int32_t *d_offsets,
                                          int32_t n_points, int32_t *d_best_index);
 
+/* ---- per-keypoint camera geometry ----------------------------------------------------------------- */
+/* replaces: the loop of FeatureHandlerFactory::Create (factories/feature_handler_factory.cpp:53-60) over
+ * MonocularCamera::UndistortPoint (camera/monocular_camera.cpp:49-61) and ::UnprojectAndUndistort (:40-47).
+ * model: ORBGPU_DISTORTION_NONE (no distortion model set), _BARREL5 (k = k1 k2 p1 p2 k3, barrel5.cpp:44-70),
+ * _FISHEYE (k = k1 k2 k3 k4, fish_eye.cpp:68-116) -- the values of camera/distortions/distortion_model_type.h;
+ * BARREL8 is rejected (the reference throws "not yet implemented", barrel8.cpp:52-55).
+ * undistorted: 2 doubles per keypoint, unprojected: 3 doubles per keypoint, ok: bit 0 / bit 1 = the bool the two
+ * reference calls return.  Where UndistortPoint returns false the reference leaves its output slot untouched
+ * (uninitialised after resize); this library writes (0, 0).  Barrel5 results are bit-exact; FishEye goes through
+ * tan() and agrees with a glibc build to a few ulp. */
+#define ORBGPU_DISTORTION_NONE (-1)
+#define ORBGPU_DISTORTION_BARREL5 0
+#define ORBGPU_DISTORTION_BARREL8 1
+#define ORBGPU_DISTORTION_FISHEYE 2
+typedef struct {
+  double fx, fy, cx, cy;
+  int32_t model;
+  int32_t reserved;
+  double k[8];
+} orbgpu_camera;
+int orbgpu_keypoint_geometry(orbgpu_ctx *ctx, const orbgpu_camera *camera, const orbgpu_keypoint *kp, int32_t n,
+                             double *undistorted, double *unprojected, uint8_t *ok);
+/* device form on the [n_frames][capacity] output of orbgpu_extract_batch_device (d_n = its per-frame counts);
+ * outputs use the same [frame][capacity] slots; asynchronous on the context's stream. */
+int orbgpu_keypoint_geometry_device(orbgpu_ctx *ctx, const orbgpu_camera *camera, const orbgpu_keypoint *d_kp,
+                                    const int32_t *d_n, int32_t n_frames, int32_t capacity, double *d_undistorted,
+                                    double *d_unprojected, uint8_t *d_ok);
+
 /* ---- vocabulary (bag of words) ------------------------------------------------------------------ */
 /* replaces: the per-feature tree descent of DBoW2Handler::Precompute (features/handlers/DBoW2/
  * dbo_w2_handler.cpp:74-93) = TemplatedVocabulary<FORB>::transform(feature, word_id, weight, nid, levelsup)

@@ -972,6 +972,93 @@ int oo_snn_match(const oo_match_args *a, int32_t *match_from, uint32_t *match_di
   return nmatches;
 }
 
+static int cam_undistort3(const oo_camera *c, const double d[3], double u[3]) {
+  if (c->model == 0) { /* Barrel5::UnDistortPoint, barrel5.cpp:44-70 */
+    const double k1 = c->k[0], k2 = c->k[1], p1 = c->k[2], p2 = c->k[3], k3 = c->k[4];
+    double x = d[0], y = d[1];
+    const double x0 = d[0], y0 = d[1];
+    u[0] = x; u[1] = y; u[2] = 1;
+    for (int j = 0; j < 10; j++) {
+      double r2 = x * x + y * y;
+      double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+      if (icdist < 0) { u[0] = x; u[1] = y; return 0; }
+      double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+      double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+      double xnew = (x0 - deltaX) * icdist;
+      double ynew = (y0 - deltaY) * icdist;
+      if (fabs(x - xnew) < 1e-7 && fabs(y - ynew) < 1e-7) { u[0] = x; u[1] = y; return 1; }
+      x = xnew;
+      y = ynew;
+    }
+    u[0] = -10000; u[1] = 10000; u[2] = -1;
+    return 0;
+  }
+  /* FishEye::UnDistortPoint, fish_eye.cpp:68-116 */
+  const double k1 = c->k[0], k2 = c->k[1], k3 = c->k[2], k4 = c->k[3];
+  double theta_d = sqrt(d[0] * d[0] + d[1] * d[1]);
+  theta_d = fmin(M_PI_2, fmax(-M_PI_2, theta_d));
+  double theta = theta_d;
+  int converged = 0;
+  for (int i = 0; i < 10; ++i) {
+    double theta_g2 = theta * theta;
+    double theta_g3 = theta_g2 * theta;
+    double theta_g4 = theta_g3 * theta;
+    double theta_g5 = theta_g4 * theta;
+    double theta_g6 = theta_g5 * theta;
+    double theta_g7 = theta_g6 * theta;
+    double theta_g8 = theta_g7 * theta;
+    double theta_g9 = theta_g8 * theta;
+    double fp = 1 + 3 * k1 * theta_g2 + 5 * k2 * theta_g4 + 7 * k3 * theta_g6 + 9 * k4 * theta_g8;
+    double theta_fix = (theta + k1 * theta_g3 + k2 * theta_g5 + k3 * theta_g7 + k4 * theta_g9 - theta_d) / fp;
+    theta -= theta_fix;
+    converged = fabs(theta_fix) < 7e-8;
+    if (converged) break;
+  }
+  if (!converged) { u[0] = -10000; u[1] = -10000; u[2] = -1; return 0; }
+  double scale = tan(theta) / theta_d;
+  int flipped = ((theta_d < 0 && theta > 0) || (theta_d > 0 && theta < 0));
+  if (converged && !flipped && scale > 0) {
+    u[0] = d[0] * scale; u[1] = d[1] * scale; u[2] = 1;
+    return 1;
+  }
+  u[0] = -10000; u[1] = -10000; u[2] = -1;
+  return 0;
+}
+
+void oo_keypoint_geometry(const oo_keypoint *kp, int n, const oo_camera *c, double *undist, double *unproj, uint8_t *ok) {
+  const double fx_inv = c->fx ? 1 / c->fx : 0, fy_inv = c->fy ? 1 / c->fy : 1; /* monocular_camera.h:107-114 */
+  for (int i = 0; i < n; i++) {
+    const double px = kp[i].x, py = kp[i].y;
+    const double up[3] = {(px - c->cx) * fx_inv, (py - c->cy) * fy_inv, 1}; /* UnprojectPoint :31-33 */
+    uint8_t flags = 0;
+    /* UndistortPoint :49-61 */
+    if (c->model < 0) {
+      undist[2 * i] = px; undist[2 * i + 1] = py;
+      flags |= 1;
+    } else {
+      double u[3];
+      if (cam_undistort3(c, up, u)) {
+        double z_inv = 1 / u[2]; /* ProjectPoint :35-38 */
+        undist[2 * i] = u[0] * z_inv * c->fx + c->cx;
+        undist[2 * i + 1] = u[1] * z_inv * c->fy + c->cy;
+        flags |= 1;
+      } else {
+        undist[2 * i] = 0; undist[2 * i + 1] = 0;
+      }
+    }
+    /* UnprojectAndUndistort :40-47 */
+    if (c->model < 0) {
+      unproj[3 * i] = up[0]; unproj[3 * i + 1] = up[1]; unproj[3 * i + 2] = up[2];
+      flags |= 2;
+    } else {
+      double u[3];
+      if (cam_undistort3(c, up, u)) flags |= 2;
+      unproj[3 * i] = u[0]; unproj[3 * i + 1] = u[1]; unproj[3 * i + 2] = u[2];
+    }
+    ok[i] = flags;
+  }
+}
+
 static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }
 
 void oo_distinctive_descriptor(const uint8_t *desc, const int32_t *offsets, int n_points, int32_t *best) {

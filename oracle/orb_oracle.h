@@ -150,6 +150,23 @@ int oo_match_area(const oo_keypoint *kp_to, const uint8_t *desc_to, int n_to, co
                   const uint8_t *desc_from, int n_from, size_t window, unsigned threshold, double ratio,
                   int32_t *match_from, uint32_t *match_dist);
 
+/* Post-extract per-keypoint geometry, factories/feature_handler_factory.cpp:53-60:
+ *   MonocularCamera::UndistortPoint        camera/monocular_camera.cpp:49-61   -> undist[2i .. 2i+1]
+ *   MonocularCamera::UnprojectAndUndistort camera/monocular_camera.cpp:40-47   -> unproj[3i .. 3i+2]
+ * with UnprojectPoint / ProjectPoint (:31-38), fx_inv_ = fx ? 1/fx : 0, fy_inv_ = fy ? 1/fy : 1
+ * (monocular_camera.h:107-114), Barrel5::UnDistortPoint (camera/distortions/barrel5.cpp:44-70) and
+ * FishEye::UnDistortPoint (camera/distortions/fish_eye.cpp:68-116).  model: -1 no distortion model, 0 BARREL5
+ * (k = k1 k2 p1 p2 k3), 2 FISHEYE (k = k1 k2 k3 k4) -- distortion_model_type.h.  ok[i] bit 0 / bit 1 = the bool the
+ * two calls return.  Where UndistortPoint fails the reference leaves its output slot untouched (uninitialised
+ * memory after resize); this restatement writes (0, 0) there. */
+typedef struct {
+  double fx, fy, cx, cy;
+  int32_t model;
+  int32_t reserved;
+  double k[8];
+} oo_camera;
+void oo_keypoint_geometry(const oo_keypoint *kp, int n, const oo_camera *cam, double *undist, double *unproj, uint8_t *ok);
+
 /* MapPoint::ComputeDistinctiveDescriptor (map/map_point.cpp:135-171) for a batch of map points: the descriptors
  * of point p are rows offsets[p] .. offsets[p+1] of desc.  best[p] = index (inside the group) of the descriptor
  * whose sorted distance row has the smallest element at position (size_t)(0.5 * (N - 1)); the first such row

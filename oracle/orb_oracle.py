@@ -258,6 +258,28 @@ def match_area(kp_to, desc_to, kp_from, desc_from, window=100, threshold=50, rat
     return mf[:len(kp_to)], md[:len(kp_to)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("model", C.c_int32),
+                ("reserved", C.c_int32), ("k", C.c_double * 8)]
+
+
+def camera(fx, fy, cx, cy, model=-1, k=()):
+    c = Camera(fx, fy, cx, cy, model, 0)
+    for i, v in enumerate(k):
+        c.k[i] = v
+    return c
+
+
+def keypoint_geometry(kp, cam):
+    kp = np.ascontiguousarray(kp, dtype=KP_DTYPE)
+    n = len(kp)
+    und = np.zeros((max(n, 1), 2), np.float64)
+    unp = np.zeros((max(n, 1), 3), np.float64)
+    ok = np.zeros(max(n, 1), np.uint8)
+    lib().oo_keypoint_geometry(_p(kp), n, C.byref(cam), _p(und), _p(unp), _p(ok))
+    return und[:n], unp[:n], ok[:n]
+
+
 def distinctive_descriptor(desc, offsets):
     desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
     offsets = np.ascontiguousarray(offsets, np.int32)

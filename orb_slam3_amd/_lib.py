@@ -40,6 +40,14 @@ class WindowArgs(C.Structure):
                 ("ratio", C.c_double)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("model", C.c_int32),
+                ("reserved", C.c_int32), ("k", C.c_double * 8)]
+
+
+DISTORTION_NONE, DISTORTION_BARREL5, DISTORTION_BARREL8, DISTORTION_FISHEYE = -1, 0, 1, 2
+
+
 class GroupArgs(C.Structure):
     _fields_ = [("to_desc", C.c_void_p), ("n_to", C.c_int32), ("from_desc", C.c_void_p), ("n_from", C.c_int32),
                 ("n_groups", C.c_int32), ("to_off", C.c_void_p), ("to_ids", C.c_void_p), ("from_off", C.c_void_p),
@@ -56,6 +64,7 @@ EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_g
            "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
            "orbgpu_match_allpairs_device", "orbgpu_vocab_create", "orbgpu_vocab_destroy", "orbgpu_bow_transform",
            "orbgpu_bow_transform_device", "orbgpu_distinctive_descriptor", "orbgpu_distinctive_descriptor_device",
+           "orbgpu_keypoint_geometry", "orbgpu_keypoint_geometry_device",
            "orbgpu_rotation_filter", "orbgpu_stage_times",
            "orbgpu_popcount_peak"]
 
@@ -93,6 +102,8 @@ def load():
         "orbgpu_match_allpairs_device": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, u32, dbl, i32, vp, vp]),
         "orbgpu_distinctive_descriptor": (i32, [vp, vp, vp, i32, vp]),
         "orbgpu_distinctive_descriptor_device": (i32, [vp, vp, vp, i32, vp]),
+        "orbgpu_keypoint_geometry": (i32, [vp, C.POINTER(Camera), vp, i32, vp, vp, vp]),
+        "orbgpu_keypoint_geometry_device": (i32, [vp, C.POINTER(Camera), vp, vp, i32, i32, vp, vp, vp]),
         "orbgpu_vocab_create": (i32, [vp, i32, vp, vp, vp, vp, i32, C.POINTER(vp)]),
         "orbgpu_vocab_destroy": (None, [vp]),
         "orbgpu_bow_transform": (i32, [vp, vp, vp, i32, i32, vp, vp]),

@@ -818,6 +818,55 @@ int orbgpu_match_groups(orbgpu_ctx *ctx, const orbgpu_group_args *a, int32_t *fr
   return ORBGPU_OK;
 }
 
+static int check_camera(orbgpu_ctx *ctx, const orbgpu_camera *cam) {
+  if (!cam) return fail(ctx, ORBGPU_E_INVALID, "null camera");
+  if (cam->model != ORBGPU_DISTORTION_NONE && cam->model != ORBGPU_DISTORTION_BARREL5 && cam->model != ORBGPU_DISTORTION_FISHEYE)
+    return fail(ctx, ORBGPU_E_INVALID, "unsupported distortion model (BARREL8 undistortion is not implemented in the reference either)");
+  return 0;
+}
+
+int orbgpu_keypoint_geometry_device(orbgpu_ctx *ctx, const orbgpu_camera *camera, const orbgpu_keypoint *d_kp,
+                                    const int32_t *d_n, int32_t n_frames, int32_t capacity, double *d_undistorted,
+                                    double *d_unprojected, uint8_t *d_ok) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  int rc = check_camera(ctx, camera);
+  if (rc) return rc;
+  if (n_frames < 0 || capacity < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (n_frames == 0 || capacity == 0) return ORBGPU_OK;
+  if (!d_kp || !d_n || !d_undistorted || !d_unprojected || !d_ok) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  launch_keypoint_geometry(ctx, *camera, d_kp, d_n, n_frames, capacity, d_undistorted, d_unprojected, d_ok);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
+int orbgpu_keypoint_geometry(orbgpu_ctx *ctx, const orbgpu_camera *camera, const orbgpu_keypoint *kp, int32_t n,
+                             double *undistorted, double *unprojected, uint8_t *ok) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  int rc = check_camera(ctx, camera);
+  if (rc) return rc;
+  if (n < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (n == 0) return ORBGPU_OK;
+  if (!kp || !undistorted || !unprojected || !ok) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  Staging st{ctx};
+  rc = st.reserve(pad256((size_t)n * sizeof(orbgpu_keypoint)) + pad256((size_t)n * 16) + pad256((size_t)n * 24) + pad256((size_t)n) + 1024);
+  if (rc) return rc;
+  orbgpu_keypoint *d_kp = st.put(kp, (size_t)n);
+  double *d_und = st.put<double>(nullptr, (size_t)n * 2);
+  double *d_unp = st.put<double>(nullptr, (size_t)n * 3);
+  uint8_t *d_ok = st.put<uint8_t>(nullptr, (size_t)n);
+  launch_keypoint_geometry(ctx, *camera, d_kp, nullptr, 1, n, d_und, d_unp, d_ok);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(undistorted, d_und, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(unprojected, d_unp, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ORBGPU_OK;
+}
+
 int orbgpu_distinctive_descriptor_device(orbgpu_ctx *ctx, const uint8_t *d_desc, const int32_t *d_offsets, int32_t n_points,
                                          int32_t *d_best_index) {
   if (!ctx) return ORBGPU_E_INVALID;

@@ -270,3 +270,99 @@ void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *
   hipLaunchKernelGGL(k_orient_describe, grid, dim3(64 * KPB), 0, c->stream, c->d_pyr, c->d_blur, c->geom, c->d_kp_xy,
                      c->d_kp_count, d_kp, d_desc, capacity, d_n_out, n_frames);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Post-extract per-keypoint geometry (factories/feature_handler_factory.cpp:53-60): MonocularCamera::UndistortPoint
+// and ::UnprojectAndUndistort (camera/monocular_camera.cpp:31-61) with Barrel5::UnDistortPoint
+// (camera/distortions/barrel5.cpp:44-70) or FishEye::UnDistortPoint (fish_eye.cpp:68-116).  One lane per keypoint,
+// double precision, no contraction; the Barrel5 path is +,-,*,/ only and therefore bit-exact, FishEye calls tan().
+namespace {
+
+__device__ __forceinline__ bool cam_undistort3(const orbgpu_camera &c, double dx, double dy, double (&u)[3]) {
+  if (c.model == ORBGPU_DISTORTION_BARREL5) {
+    const double k1 = c.k[0], k2 = c.k[1], p1 = c.k[2], p2 = c.k[3], k3 = c.k[4];
+    double x = dx, y = dy;
+    u[2] = 1;
+    for (int j = 0; j < 10; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+      if (icdist < 0) { u[0] = x; u[1] = y; return false; }
+      const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+      const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+      const double xnew = (dx - deltaX) * icdist;
+      const double ynew = (dy - deltaY) * icdist;
+      if (fabs(x - xnew) < 1e-7 && fabs(y - ynew) < 1e-7) { u[0] = x; u[1] = y; return true; }
+      x = xnew;
+      y = ynew;
+    }
+    u[0] = -10000; u[1] = 10000; u[2] = -1;
+    return false;
+  }
+  const double k1 = c.k[0], k2 = c.k[1], k3 = c.k[2], k4 = c.k[3];
+  const double pi_2 = 1.57079632679489661923;
+  double theta_d = sqrt(dx * dx + dy * dy);
+  theta_d = fmin(pi_2, fmax(-pi_2, theta_d));
+  double theta = theta_d;
+  bool converged = false;
+  for (int i = 0; i < 10; ++i) {
+    const double g2 = theta * theta, g3 = g2 * theta, g4 = g3 * theta, g5 = g4 * theta, g6 = g5 * theta, g7 = g6 * theta,
+                 g8 = g7 * theta, g9 = g8 * theta;
+    const double fp = 1 + 3 * k1 * g2 + 5 * k2 * g4 + 7 * k3 * g6 + 9 * k4 * g8;
+    const double theta_fix = (theta + k1 * g3 + k2 * g5 + k3 * g7 + k4 * g9 - theta_d) / fp;
+    theta -= theta_fix;
+    converged = fabs(theta_fix) < 7e-8;
+    if (converged) break;
+  }
+  if (!converged) { u[0] = -10000; u[1] = -10000; u[2] = -1; return false; }
+  const double scale = tan(theta) / theta_d;
+  const bool flipped = (theta_d < 0 && theta > 0) || (theta_d > 0 && theta < 0);
+  if (!flipped && scale > 0) {
+    u[0] = dx * scale; u[1] = dy * scale; u[2] = 1;
+    return true;
+  }
+  u[0] = -10000; u[1] = -10000; u[2] = -1;
+  return false;
+}
+
+// kp: [n_frames][capacity]; n == nullptr: a single flat array of `capacity` keypoints
+__global__ __launch_bounds__(256) void k_keypoint_geometry(orbgpu_camera c, const orbgpu_keypoint *__restrict__ kp,
+                                                           const int *__restrict__ n, int capacity,
+                                                           double *__restrict__ undist, double *__restrict__ unproj,
+                                                           uint8_t *__restrict__ ok) {
+  const int f = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int count = n ? min(n[f], capacity) : capacity;
+  if (i >= count) return;
+  const size_t s = (size_t)f * capacity + i;
+  const double fx_inv = c.fx != 0 ? 1 / c.fx : 0, fy_inv = c.fy != 0 ? 1 / c.fy : 1;
+  const double px = kp[s].x, py = kp[s].y;
+  const double ux = (px - c.cx) * fx_inv, uy = (py - c.cy) * fy_inv;
+  uint8_t flags = 0;
+  double u[3];
+  if (c.model < 0) {
+    undist[2 * s] = px; undist[2 * s + 1] = py;
+    unproj[3 * s] = ux; unproj[3 * s + 1] = uy; unproj[3 * s + 2] = 1;
+    flags = 3;
+  } else {
+    const bool good = cam_undistort3(c, ux, uy, u);  // both reference calls run the same undistortion
+    if (good) {
+      const double z_inv = 1 / u[2];
+      undist[2 * s] = u[0] * z_inv * c.fx + c.cx;
+      undist[2 * s + 1] = u[1] * z_inv * c.fy + c.cy;
+      flags = 3;
+    } else {
+      undist[2 * s] = 0; undist[2 * s + 1] = 0;
+    }
+    unproj[3 * s] = u[0]; unproj[3 * s + 1] = u[1]; unproj[3 * s + 2] = u[2];
+  }
+  ok[s] = flags;
+}
+
+}  // namespace
+
+void launch_keypoint_geometry(const orbgpu_ctx *c, const orbgpu_camera &cam, const orbgpu_keypoint *d_kp, const int *d_n,
+                              int n_frames, int capacity, double *d_undist, double *d_unproj, uint8_t *d_ok) {
+  if (n_frames <= 0 || capacity <= 0) return;
+  hipLaunchKernelGGL(k_keypoint_geometry, dim3((capacity + 255) / 256, n_frames), dim3(256), 0, c->stream, cam, d_kp, d_n,
+                     capacity, d_undist, d_unproj, d_ok);
+}

@@ -143,6 +143,8 @@ void launch_cell_detect(const orbgpu_ctx *c, int n_frames);
 void launch_blur(const orbgpu_ctx *c, int n_frames, hipStream_t stream);
 void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                             int *d_n_out);
+void launch_keypoint_geometry(const orbgpu_ctx *c, const orbgpu_camera &cam, const orbgpu_keypoint *d_kp, const int *d_n,
+                              int n_frames, int capacity, double *d_undist, double *d_unproj, uint8_t *d_ok);
 void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t frame_stride, int stride, int n_frames);
 
 // device quadtree (k_quadtree.hip); budget = per-level feature budget.  Returns 0 or -1 (LDS too large)

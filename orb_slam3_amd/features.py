@@ -372,3 +372,28 @@ def ComputeDistinctiveDescriptors(feature_extractor, descriptor_groups):
     feature_extractor._check(feature_extractor._lib.orbgpu_distinctive_descriptor(
         feature_extractor.handle, _lib.ptr(desc), _lib.ptr(offsets), len(groups), _lib.ptr(best)))
     return best[:len(groups)]
+
+
+class MonocularCamera:
+    """camera::MonocularCamera (camera/monocular_camera.h) as far as the feature path uses it: intrinsics plus an
+    optional distortion model, and the per-keypoint loop of FeatureHandlerFactory::Create
+    (factories/feature_handler_factory.cpp:53-60) as one call."""
+
+    def __init__(self, fx, fy, cx, cy, model=_lib.DISTORTION_NONE, k=()):
+        self._c = _lib.Camera(float(fx), float(fy), float(cx), float(cy), int(model), 0)
+        for i, v in enumerate(k):
+            self._c.k[i] = float(v)
+
+    def UndistortFeatures(self, feature_extractor, features):
+        """fills features.undistorted_keypoints / undistorted_and_unprojected_keypoints; returns the ok flags
+        (bit 0: UndistortPoint, bit 1: UnprojectAndUndistort)"""
+        n = features.Size()
+        kp = np.ascontiguousarray(features.keypoints)
+        und = np.zeros((max(n, 1), 2), np.float64)
+        unp = np.zeros((max(n, 1), 3), np.float64)
+        ok = np.zeros(max(n, 1), np.uint8)
+        feature_extractor._check(feature_extractor._lib.orbgpu_keypoint_geometry(
+            feature_extractor.handle, C.byref(self._c), _lib.ptr(kp), n, _lib.ptr(und), _lib.ptr(unp), _lib.ptr(ok)))
+        features.undistorted_keypoints = und[:n]
+        features.undistorted_and_unprojected_keypoints = unp[:n]
+        return ok[:n]

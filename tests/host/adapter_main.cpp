@@ -12,6 +12,7 @@
 #include "hip_snn_matcher.h"
 #include "hip_bow_vocabulary.h"
 #include "hip_map_point.h"
+#include "hip_monocular_camera.h"
 
 using namespace orb_slam3;
 
@@ -119,6 +120,12 @@ int main(int argc, char ** argv) {
   }
   const std::vector<int32_t> distinctive = map::HipComputeDistinctiveDescriptors(hip->context(), groups);
 
+  // FeatureHandlerFactory::Create, feature_handler_factory.cpp:53-60, with a Barrel5 camera
+  orbgpu_camera cam{};
+  cam.fx = 258.6; cam.fy = 258.2; cam.cx = 160.2; cam.cy = 120.1; cam.model = ORBGPU_DISTORTION_BARREL5;
+  cam.k[0] = -0.28; cam.k[1] = 0.07; cam.k[2] = 2e-4; cam.k[3] = 1.8e-5; cam.k[4] = 0.0;
+  const std::vector<uint8_t> geom_ok = camera::HipUndistortFeatures(hip->context(), cam, f1);
+
   std::ofstream o(argv[6], std::ios::binary);
   for (const features::Features * f : {&f0, &f1}) {
     put(o, (int32_t)f->Size());
@@ -137,6 +144,12 @@ int main(int argc, char ** argv) {
   for (const auto & kv : tfv) { put(o, (int32_t)kv.first); put(o, (int32_t)kv.second.size()); for (unsigned i : kv.second) put(o, (int32_t)i); }
   put(o, (int32_t)distinctive.size());
   for (int32_t b : distinctive) put(o, b);
+  put(o, (int32_t)geom_ok.size());
+  for (size_t i = 0; i < geom_ok.size(); ++i) {
+    put(o, geom_ok[i]);
+    put(o, f1.undistorted_keypoints[i][0]); put(o, f1.undistorted_keypoints[i][1]);
+    for (int c = 0; c < 3; ++c) put(o, f1.undistorted_and_unprojected_keypoints[i][c]);
+  }
   // scalar helpers
   put(o, (uint32_t)fe->PredictScale(1.0, 3.0)); put(o, fe->GetAcceptableSquareError(3));
   features::DescriptorType a, b; std::memcpy(a.d, f0.descriptors.data(), 32); std::memcpy(b.d, f0.descriptors.data() + 32, 32);

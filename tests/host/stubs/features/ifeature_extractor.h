@@ -65,6 +65,8 @@ class Features {  // src/features/features.h:23-54
   Features(precision_t width, precision_t height) : image_width(width), image_height(height) {}
   DescriptorSet descriptors;
   std::vector<KeyPoint> keypoints;
+  std::vector<TPoint2D> undistorted_keypoints;
+  std::vector<TPoint3D> undistorted_and_unprojected_keypoints;
   precision_t image_width, image_height;
   size_t Size() const { return keypoints.size(); }
 };

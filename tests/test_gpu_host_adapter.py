@@ -121,6 +121,12 @@ def test_cpp_adapter_end_to_end(oracle, tmp_path):
     grp = [d0[g::7] for g in range(7)] + [np.zeros((0, 32), np.uint8)]
     off = np.cumsum([0] + [len(g) for g in grp]).astype(np.int32)
     assert got_best == oracle.distinctive_descriptor(np.concatenate(grp), off).tolist() and got_best[-1] == -1
+    n_geom = take("i")
+    assert n_geom == len(k1)
+    rec = np.frombuffer(buf, np.dtype([("ok", "u1"), ("und", "<f8", 2), ("unp", "<f8", 3)]), n_geom, pos)
+    pos += n_geom * 41
+    wund, wunp, wok = oracle.keypoint_geometry(k1, oracle.camera(258.6, 258.2, 160.2, 120.1, 0, (-0.28, 0.07, 2e-4, 1.8e-5, 0.0)))
+    assert np.array_equal(rec["ok"], wok) and np.array_equal(rec["und"], wund) and np.array_equal(rec["unp"], wunp)
     assert take("I") == oracle.predict_scale(1.0, 3.0, 1.2, 8)
     s3 = 1.0 * 1.2 * 1.2 * 1.2
     assert take("d") == s3 * s3

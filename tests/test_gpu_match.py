@@ -245,3 +245,40 @@ def test_distinctive_descriptor_parity(oracle, fe):
     assert np.array_equal(got, want)
     assert len(ComputeDistinctiveDescriptors(fe, [])) == 0
     assert ComputeDistinctiveDescriptors(fe, [np.zeros((0, 32), np.uint8)])[0] == -1
+
+
+def test_keypoint_geometry_parity(oracle, fe):
+    """orbgpu_keypoint_geometry (UndistortPoint + UnprojectAndUndistort per keypoint) against the oracle:
+    bit-exact without a model and for Barrel5 (+, -, *, / only); FishEye goes through tan(): <= 4 ulp."""
+    from orb_slam3_amd.features import Features, MonocularCamera
+    from orb_slam3_amd._lib import KP_DTYPE, OrbGpuError
+    from test_oracle import CAMERAS
+    rng = np.random.default_rng(3)
+    n = 5000
+    f = Features(640, 480)
+    f.keypoints = np.zeros(n, KP_DTYPE)
+    f.keypoints["x"], f.keypoints["y"] = rng.uniform(0, 640, n), rng.uniform(0, 480, n)
+    f.keypoints["x"][:3], f.keypoints["y"][:3] = (320.5, 0, 639), (240.25, 0, 479)
+    okp = np.zeros(n, oracle.KP_DTYPE)
+    okp["x"], okp["y"] = f.keypoints["x"], f.keypoints["y"]
+    for model, k in CAMERAS:
+        cam = MonocularCamera(517.3, 516.5, 320.5, 240.25, model, k)
+        ok = cam.UndistortFeatures(fe, f)
+        wund, wunp, wok = oracle.keypoint_geometry(okp, oracle.camera(517.3, 516.5, 320.5, 240.25, model, k))
+        if model == 2:
+            # a point whose last Newton step sits at the 7e-8 convergence limit may flip with a 1-ulp tan difference
+            same = ok == wok
+            assert same.mean() > 0.999
+            # unprojected rays: a few ulp of tan(); pixels add c_x to f_x * u (cancellation near the image origin), so
+            # their error is a few ulp of the image size, not of the value
+            got, want = f.undistorted_and_unprojected_keypoints[same], wunp[same]
+            assert (np.abs(got - want) <= 4 * np.spacing(np.abs(want))).all()
+            assert (np.abs(f.undistorted_keypoints[same] - wund[same]) <= 1e-12).all()
+        else:
+            assert np.array_equal(ok, wok)
+            assert np.array_equal(f.undistorted_keypoints, wund)
+            assert np.array_equal(f.undistorted_and_unprojected_keypoints, wunp)
+    with pytest.raises(OrbGpuError):
+        MonocularCamera(500, 500, 320, 240, 1, (0,) * 8).UndistortFeatures(fe, f)     # BARREL8
+    f0 = Features(640, 480)
+    assert len(MonocularCamera(500, 500, 320, 240).UndistortFeatures(fe, f0)) == 0

@@ -476,3 +476,89 @@ def test_distinctive_descriptor_vs_literal(oracle):
             if median < best_median:
                 best_median, best_idx = median, i
         assert got[p] == best_idx
+
+
+def _py_undistort3(model, k, d):
+    """camera/distortions/barrel5.cpp:44-70 and fish_eye.cpp:68-116 in Python floats (IEEE double, no FMA)"""
+    import math
+
+    def div(a, b):          # IEEE division (Python raises on a zero divisor)
+        if b != 0:
+            return a / b
+        return math.nan if a == 0 or a != a else math.copysign(math.inf, a) * math.copysign(1.0, b)
+    if model == 0:
+        k1, k2, p1, p2, k3 = k[:5]
+        x, y = d[0], d[1]
+        x0, y0 = d[0], d[1]
+        for _ in range(10):
+            r2 = x * x + y * y
+            icdist = div(1., 1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            if icdist < 0:
+                return False, (x, y, 1.0)
+            dX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+            dY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+            xn, yn = (x0 - dX) * icdist, (y0 - dY) * icdist
+            if abs(x - xn) < 1e-7 and abs(y - yn) < 1e-7:
+                return True, (x, y, 1.0)
+            x, y = xn, yn
+        return False, (-10000.0, 10000.0, -1.0)
+    k1, k2, k3, k4 = k[:4]
+    theta_d = math.sqrt(d[0] * d[0] + d[1] * d[1])
+    theta_d = min(math.pi / 2, max(-math.pi / 2, theta_d))
+    theta, conv = theta_d, False
+    for _ in range(10):
+        g2 = theta * theta; g3 = g2 * theta; g4 = g3 * theta; g5 = g4 * theta
+        g6 = g5 * theta; g7 = g6 * theta; g8 = g7 * theta; g9 = g8 * theta
+        fp = 1 + 3 * k1 * g2 + 5 * k2 * g4 + 7 * k3 * g6 + 9 * k4 * g8
+        fix = div(theta + k1 * g3 + k2 * g5 + k3 * g7 + k4 * g9 - theta_d, fp)
+        theta -= fix
+        conv = abs(fix) < 7e-8
+        if conv:
+            break
+    if not conv:
+        return False, (-10000.0, -10000.0, -1.0)
+    scale = div(math.tan(theta), theta_d)
+    flipped = (theta_d < 0 and theta > 0) or (theta_d > 0 and theta < 0)
+    if not flipped and scale > 0:
+        return True, (d[0] * scale, d[1] * scale, 1.0)
+    return False, (-10000.0, -10000.0, -1.0)
+
+
+CAMERAS = [
+    (-1, ()),                                               # no distortion model
+    (0, (-0.28, 0.07, 2e-4, 1.8e-5, 0.0)),                   # TUM-like radial-tangential
+    (0, (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)),         # Freiburg1
+    (0, (-80.0, 0.0, 0.0, 0.0, 0.0)),                         # absurd k1: icdist < 0 / no convergence on the rim
+    (2, (0.0034, 0.0007, -0.0021, 0.0002)),                  # TUM-VI-like fisheye
+    (2, (2.5, -9.0, 30.0, -40.0)),                            # ill-conditioned: some points do not converge
+]
+
+
+def test_keypoint_geometry_vs_literal(oracle):
+    """oo_keypoint_geometry against a Python transcription of monocular_camera.cpp:31-61 + the distortion models."""
+    rng = np.random.default_rng(2)
+    n = 600
+    kp = np.zeros(n, oracle.KP_DTYPE)
+    kp["x"], kp["y"] = rng.uniform(0, 640, n) * 1.2 ** rng.integers(0, 3, n), rng.uniform(0, 480, n)
+    kp["x"][:3], kp["y"][:3] = (320.5, 0, 639), (240.25, 0, 479)       # the principal point itself, corners
+    for model, k in CAMERAS:
+        fx, fy, cx, cy = 517.3, 516.5, 320.5, 240.25
+        cam = oracle.camera(fx, fy, cx, cy, model, k)
+        und, unp, ok = oracle.keypoint_geometry(kp, cam)
+        fx_inv, fy_inv = 1 / fx, 1 / fy
+        n_fail = 0
+        for i in range(n):
+            up = ((kp["x"][i] - cx) * fx_inv, (kp["y"][i] - cy) * fy_inv, 1.0)
+            if model < 0:
+                assert tuple(und[i]) == (kp["x"][i], kp["y"][i]) and tuple(unp[i]) == up and ok[i] == 3
+                continue
+            good, u = _py_undistort3(model, k, up)
+            assert tuple(unp[i]) == u and ok[i] == (3 if good else 0)
+            if good:
+                z_inv = 1 / u[2]
+                assert tuple(und[i]) == (u[0] * z_inv * fx + cx, u[1] * z_inv * fy + cy)
+            else:
+                n_fail += 1
+                assert tuple(und[i]) == (0.0, 0.0)
+        if k and abs(k[0]) > 2:
+            assert n_fail > 0          # the failure branches are really exercised
