@@ -155,11 +155,13 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
           r[12] = pair_bytes<3>(w[3]); r[13] = pair_bytes<3>(w[4]); r[14] = pair_bytes<4>(w[5]); r[15] = pair_bytes<5>(w[6]);
         }
         const u16x2 v = pr == 0 ? pair_bytes<4>(w[3]) : pair_bytes<6>(w[3]);
-        // dark 9-arc needs min(ring_k, ring_k+8) < v - t for all 8 opposite pairs, bright max(...) > v + t
+        // a dark 9-arc needs min(ring_k, ring_k+8) < v - t for every opposite pair, a bright one max(...) > v + t.
+        // Only the 4 even pairs are tested: measured on the bench frames, 8 pairs reject a little more (13 % survive)
+        // but cost more than the extra full scores do (0.45 ms vs 0.39 ms per batch); 2 or 3 pairs are worse again
         u16x2 mx_of_min = __builtin_elementwise_min(r[0], r[8]);
         u16x2 mn_of_max = __builtin_elementwise_max(r[0], r[8]);
 #pragma unroll
-        for (int k = 1; k < 8; k++) {
+        for (int k = 2; k < 8; k += 2) {
           mx_of_min = __builtin_elementwise_max(mx_of_min, __builtin_elementwise_min(r[k], r[k + 8]));
           mn_of_max = __builtin_elementwise_min(mn_of_max, __builtin_elementwise_max(r[k], r[k + 8]));
         }
