@@ -59,6 +59,28 @@ BODY(k_xor_e64, "v_xor_b32_e64 %0, %0, %4\n v_xor_b32_e64 %1, %1, %4\n v_xor_b32
 BODY(k_sub_f32_sdwa, "v_sub_f32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_sub_f32_sdwa %1, %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_sub_f32_sdwa %2, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_sub_f32_sdwa %3, %3, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
 BODY(k_min_u32_sdwa, "v_min_u32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_min_u32_sdwa %1, %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_min_u32_sdwa %2, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_min_u32_sdwa %3, %3, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
 
+// scalar ALU: 4 independent s_add_u32 per block
+__global__ __launch_bounds__(256) void k_salu(unsigned *sink, int iters) {
+  unsigned a0 = blockIdx.x, a1 = blockIdx.x * 3u + 1u, a2 = blockIdx.x * 5u + 2u, a3 = blockIdx.x * 7u + 3u;
+  unsigned b = blockIdx.x + 11u;
+  for (int i = 0; i < iters; i++) {
+    REP8(asm volatile("s_add_u32 %0, %0, %4\n s_add_u32 %1, %1, %4\n s_add_u32 %2, %2, %4\n s_add_u32 %3, %3, %4"
+                      : "+s"(a0), "+s"(a1), "+s"(a2), "+s"(a3) : "s"(b) : "scc");)
+  }
+  if ((a0 ^ a1 ^ a2 ^ a3) == 0x12345678u) sink[0] = a0;
+}
+// scalar and vector ALU work interleaved in one wave: does the scalar stream cost vector issue slots?
+__global__ __launch_bounds__(256) void k_salu_valu(unsigned *sink, int iters) {
+  unsigned a0 = blockIdx.x, a1 = blockIdx.x * 3u + 1u;
+  unsigned v0 = threadIdx.x, v1 = threadIdx.x * 3u, c = threadIdx.x ^ 0x55u;
+  unsigned b = blockIdx.x + 11u;
+  for (int i = 0; i < iters; i++) {
+    REP8(asm volatile("s_add_u32 %0, %0, %4\n v_min_u32 %2, %2, %5\n s_add_u32 %1, %1, %4\n v_min_u32 %3, %3, %5"
+                      : "+s"(a0), "+s"(a1), "+v"(v0), "+v"(v1) : "s"(b), "v"(c) : "scc");)
+  }
+  if ((a0 ^ a1 ^ v0 ^ v1) == 0x12345678u) sink[0] = a0;
+}
+
 typedef void (*kern_t)(unsigned *, int);
 
 static void run(const char *name, kern_t k, unsigned *sink, int cus, double mhz) {
@@ -94,6 +116,7 @@ int main() {
   R(k_add_u32); R(k_sub_u32); R(k_and_b32); R(k_or_b32); R(k_lshlrev); R(k_lshrrev); R(k_max_u32); R(k_add_f32);
   R(k_mul_f32); R(k_max_f32); R(k_mul_u24); R(k_mov); R(k_cndmask); R(k_add3); R(k_and_or); R(k_bfe); R(k_xor_e64);
    R(k_sub_f32_sdwa); R(k_min_u32_sdwa);
+  R(k_salu); R(k_salu_valu);
   hipFree(sink);
   return 0;
 }
