@@ -48,7 +48,21 @@ __device__ __forceinline__ int fast_score16(int v, const int (&r)[16], int min_t
   return s >= min_thr ? s : 0;
 }
 
-// the same score for a pixel that already passed the opposite-pair test (no early-out)
+// three-input min / max, pinned: left to itself the compiler shares two-input partial results between neighbouring
+// windows and ends up with twice as many instructions
+__device__ __forceinline__ int vmin3(int a, int b, int c) {
+  int r;
+  asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ int vmax3(int a, int b, int c) {
+  int r;
+  asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// the same score for a pixel that already passed the opposite-pair test (no early-out): 16 sub + 64 min3/max3 for
+// the 9-windows of both polarities + 16 for the two reductions
 __device__ __forceinline__ int fast_score16_full(int v, const int (&r)[16], int min_thr) {
   int d[16];
 #pragma unroll
@@ -56,15 +70,23 @@ __device__ __forceinline__ int fast_score16_full(int v, const int (&r)[16], int 
   int mn3[16], mx3[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    mn3[k] = imin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-    mx3[k] = imax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    mn3[k] = vmin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    mx3[k] = vmax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
   }
-  int m_dark = -255, m_brightneg = 255;
+  int mn9[16], mx9[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    m_dark = max(m_dark, imin3(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
-    m_brightneg = min(m_brightneg, imax3(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
+    mn9[k] = vmin3(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
+    mx9[k] = vmax3(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
   }
+  int m_dark = vmax3(mn9[0], mn9[1], mn9[2]), m_brightneg = vmin3(mx9[0], mx9[1], mx9[2]);
+#pragma unroll
+  for (int k = 3; k < 15; k += 2) {
+    m_dark = vmax3(m_dark, mn9[k], mn9[k + 1]);
+    m_brightneg = vmin3(m_brightneg, mx9[k], mx9[k + 1]);
+  }
+  m_dark = max(m_dark, mn9[15]);
+  m_brightneg = min(m_brightneg, mx9[15]);
   int s = max(m_dark, -m_brightneg) - 1;
   return s >= min_thr ? s : 0;
 }
