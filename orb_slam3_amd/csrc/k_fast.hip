@@ -272,20 +272,21 @@ constexpr int CELL_DW = 16;
 constexpr int CELL_PITCH = CELL_DW * 4;
 constexpr int CQ_CAP = 512;        // queue entries; denser cells take the division-based dense path
 constexpr int CELLS_PER_WG = 4;
-__host__ __device__ constexpr size_t cell_lds_bytes(int cell_rows) { return (size_t)cell_rows * (CELL_PITCH + 16) + CQ_CAP * 2; }
+// per wave: (cell_rows + 3) staged rows (two zero rows above, one below), two ballot arrays, the queue
+__host__ __device__ constexpr size_t cell_lds_bytes(int cell_rows) { return (size_t)(cell_rows + 3) * CELL_PITCH + (size_t)cell_rows * 16 + CQ_CAP * 2; }
 
 __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t *__restrict__ score,
                                                                    const unsigned *__restrict__ nzmask, DeviceGeom g,
                                                                    CellEntry *__restrict__ cells,
                                                                    unsigned *__restrict__ cands, int n_frames,
                                                                    int cell_rows) {
-  // dynamic LDS, per wave: score rectangle [cell_rows][16 dwords] | NMS ballots hi, lo [cell_rows] | queue [CQ_CAP]
+  // dynamic LDS, per wave: score rectangle [cell_rows + 3][16 dwords] | NMS ballots hi, lo [cell_rows] | queue [CQ_CAP]
   extern __shared__ __attribute__((aligned(16))) unsigned char cd_lds[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   unsigned char *wbase = cd_lds + (size_t)wave * cell_lds_bytes(cell_rows);
   unsigned *s32 = reinterpret_cast<unsigned *>(wbase);
-  const uint8_t *s8 = reinterpret_cast<const uint8_t *>(s32);
-  unsigned long long *m_hi = reinterpret_cast<unsigned long long *>(wbase + (size_t)cell_rows * CELL_PITCH);
+  const uint8_t *sc = reinterpret_cast<const uint8_t *>(s32) + 2 * CELL_PITCH;  // rectangle row 0, staged column 0
+  unsigned long long *m_hi = reinterpret_cast<unsigned long long *>(wbase + (size_t)(cell_rows + 3) * CELL_PITCH);
   unsigned long long *m_lo = m_hi + cell_rows;
   unsigned short *queue = reinterpret_cast<unsigned short *>(m_lo + cell_rows);
   int f, c, l = 0;
@@ -352,8 +353,10 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
   for (int u = 0; u < 16; u++) {
     const int r = 4 * u + rsub;
     if (4 * u < rh)
-      if (r < rh) s32[r * CELL_DW + dd] = w[u];
+      if (r < rh) s32[(r + 2) * CELL_DW + dd] = w[u];
   }
+  if (lane < 2 * CELL_DW) s32[lane] = 0;                             // the two zero rows above the rectangle
+  else if (lane < 3 * CELL_DW) s32[(rh + 2) * CELL_DW + (lane - 2 * CELL_DW)] = 0;  // and the one below
   if (nq <= CQ_CAP) {
     int pos = incl - cnt;
     unsigned long long bits = rowbits;
@@ -379,10 +382,8 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
       cx = e & 63;
     }
   };
-  auto at = [&](int yy, int cx) -> int {
-    return (yy >= 0 && yy < rh && cx >= cxa && cx < cxa + rw) ? (int)s8[yy * CELL_PITCH + cx] : 0;
-  };
-
+  // the rectangle sits between zero rows (two above, one below) and every staged row ends in zero bytes (columns
+  // >= cxa + rw <= 63), so the 8 neighbours are read without bounds checks: outside the rectangle they are 0
   int tot_hi = 0, tot_lo = 0;
   for (int ch = 0; ch < nchunks; ch++) {
     const int k = ch * 64 + lane;
@@ -390,21 +391,15 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
     if (k < n_ent) {
       int yy, cx;
       entry(k, yy, cx);
-      const int v = s8[yy * CELL_PITCH + cx];
-      if (v >= t_lo) {  // the score map holds 0 below fast_min
-        int nmax_lo = 0, nmax_hi = 0;
-#pragma unroll
-        for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-          for (int dx = -1; dx <= 1; dx++) {
-            if (dx == 0 && dy == 0) continue;
-            const int n = at(yy + dy, cx + dx);
-            nmax_lo = max(nmax_lo, n);  // n is 0 or >= t_lo
-            nmax_hi = max(nmax_hi, n >= t_hi ? n : 0);
-          }
-        kl = v > nmax_lo;
-        kh = v >= t_hi && v > nmax_hi;
-      }
+      const uint8_t *c = sc + yy * CELL_PITCH + cx;
+      const int v = c[0];
+      // 3x3 non-maximum suppression.  One sweep serves both thresholds: for v >= t_hi, "greater than every
+      // neighbour that is itself >= t_hi" and "greater than every neighbour" are the same condition
+      const int n0 = vmax3(c[-CELL_PITCH - 1], c[-CELL_PITCH], c[-CELL_PITCH + 1]);
+      const int n1 = vmax3(c[-1], c[1], c[CELL_PITCH - 1]);
+      const int n2 = vmax3(c[CELL_PITCH], c[CELL_PITCH + 1], n0);
+      kl = v >= t_lo && v > max(n1, n2);  // the score map holds 0 below fast_min
+      kh = kl && v >= t_hi;
     }
     const unsigned long long bh = __ballot(kh), bl = __ballot(kl);
     tot_hi += __popcll(bh);
@@ -432,7 +427,7 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
       int yy, cx;
       entry(ch * 64 + lane, yy, cx);
       out[run + __popcll(m & below)] =
-          pack_cand(x0 + (cx - cxa) - ORB_MIN_BORDER, y0 + yy - ORB_MIN_BORDER, s8[yy * CELL_PITCH + cx]);
+          pack_cand(x0 + (cx - cxa) - ORB_MIN_BORDER, y0 + yy - ORB_MIN_BORDER, sc[yy * CELL_PITCH + cx]);
     }
     run += __popcll(m);
   }
