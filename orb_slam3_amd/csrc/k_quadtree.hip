@@ -13,6 +13,8 @@
 //   finally (:486-501)  the first maximum-response key of each node is emitted in list order.
 // Parallel decomposition: nodes with many keys are partitioned by a whole wave (ballot prefix compaction),
 // small nodes by single lanes; list positions come from workgroup-wide prefix sums.
+#include <type_traits>
+
 #include "orbgpu_internal.h"
 
 namespace {
@@ -35,8 +37,12 @@ __device__ __forceinline__ int key_x(unsigned k) { return (int)(k & 0xfffu); }
 __device__ __forceinline__ int key_y(unsigned k) { return (int)((k >> 12) & 0xfffu); }
 __device__ __forceinline__ int key_resp(unsigned k) { return (int)(k >> 24); }
 
+// key buffers carry their address space in the type: LDS (3) or global (1), so that the accesses are ds_ / global_
+// instructions and not flat ones
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef __attribute__((address_space(1))) unsigned glb_u32;
+
 struct QShared {
-  unsigned *keys[2];
   QNode *cur, *nxt;
   uint4 *qc;            // quadrant counts of list entry i
   u64 *pre;             // packed prefix sums per entry (3 x 21 bit)
@@ -79,11 +85,13 @@ __device__ __forceinline__ int quadrant(unsigned key, int mx, int my) {
 }
 
 // stable 4-way partition of src[beg, beg+cnt) into dst[beg, ...) by a whole wave; returns the quadrant counts
-__device__ uint4 partition_wave(const unsigned *src, unsigned *dst, int beg, int cnt, int mx, int my) {
+template <class KT>
+__device__ __forceinline__ uint4 partition_wave(const KT *src, KT *dst, int beg, int cnt, int mx, int my) {
   const int lane = threadIdx.x & 63;
   const u64 below = (1ull << lane) - 1ull;
   int c[4] = {0, 0, 0, 0};
-  for (int k0 = 0; k0 < cnt; k0 += 64) {
+#pragma unroll 4
+  for (int k0 = 0; k0 < cnt; k0 += 64) {  // unrolled: the key loads of four steps are in flight together
     const int k = k0 + lane;
     const bool ok = k < cnt;
     const int q = ok ? quadrant(src[beg + k], mx, my) : -1;
@@ -95,6 +103,7 @@ __device__ uint4 partition_wave(const unsigned *src, unsigned *dst, int beg, int
   o[1] = o[0] + c[0];
   o[2] = o[1] + c[1];
   o[3] = o[2] + c[2];
+#pragma unroll 4
   for (int k0 = 0; k0 < cnt; k0 += 64) {
     const int k = k0 + lane;
     const bool ok = k < cnt;
@@ -111,8 +120,10 @@ __device__ uint4 partition_wave(const unsigned *src, unsigned *dst, int beg, int
 }
 
 // the same by one lane
-__device__ uint4 partition_lane(const unsigned *src, unsigned *dst, int beg, int cnt, int mx, int my) {
+template <class KT>
+__device__ __forceinline__ uint4 partition_lane(const KT *src, KT *dst, int beg, int cnt, int mx, int my) {
   int c[4] = {0, 0, 0, 0};
+#pragma unroll 4
   for (int k = 0; k < cnt; k++) {
     const int q = quadrant(src[beg + k], mx, my);
     c[0] += q == 0; c[1] += q == 1; c[2] += q == 2; c[3] += q == 3;
@@ -122,6 +133,7 @@ __device__ uint4 partition_lane(const unsigned *src, unsigned *dst, int beg, int
   o[1] = o[0] + c[0];
   o[2] = o[1] + c[1];
   o[3] = o[2] + c[2];
+#pragma unroll 4
   for (int k = 0; k < cnt; k++) {
     const unsigned key = src[beg + k];
     const int q = quadrant(key, mx, my);
@@ -141,19 +153,84 @@ __device__ __forceinline__ void node_mid(const QNode &P, int &mx, int &my) {
   my = P.y0 + ((P.y1 - P.y0 + 1) >> 1);  // :607
 }
 
+// stable 4-way partition of a very large node by the whole workgroup: every wave takes a contiguous quarter of the
+// keys, counts its quadrants, and scatters behind the waves before it.  All threads call it together.
+constexpr int QT_BIG = 2048;
+template <class KT>
+__device__ __forceinline__ uint4 partition_block(const KT *src, KT *dst, int beg, int cnt, int mx, int my) {
+  __shared__ int wc[QT_WAVES][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u64 below = (1ull << lane) - 1ull;
+  const int chunk = (((cnt + QT_WAVES - 1) / QT_WAVES) + 63) & ~63;
+  const int b0 = min(wave * chunk, cnt), b1 = min(b0 + chunk, cnt);
+  int c[4] = {0, 0, 0, 0};
+#pragma unroll 4
+  for (int k0 = b0; k0 < b1; k0 += 64) {
+    const int k = k0 + lane;
+    const int q = k < b1 ? quadrant(src[beg + k], mx, my) : -1;
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) c[qq] += __popcll(__ballot(q == qq));
+  }
+  if (lane < 4) wc[wave][lane] = lane == 0 ? c[0] : lane == 1 ? c[1] : lane == 2 ? c[2] : c[3];
+  __syncthreads();
+  int tot[4], o[4];
+#pragma unroll
+  for (int qq = 0; qq < 4; qq++) {
+    tot[qq] = 0;
+    o[qq] = 0;
+    for (int w = 0; w < QT_WAVES; w++) {
+      if (w < wave) o[qq] += wc[w][qq];
+      tot[qq] += wc[w][qq];
+    }
+  }
+  o[0] += beg;
+  o[1] += beg + tot[0];
+  o[2] += beg + tot[0] + tot[1];
+  o[3] += beg + tot[0] + tot[1] + tot[2];
+#pragma unroll 4
+  for (int k0 = b0; k0 < b1; k0 += 64) {
+    const int k = k0 + lane;
+    const bool ok = k < b1;
+    const unsigned key = ok ? src[beg + k] : 0u;
+    const int q = ok ? quadrant(key, mx, my) : -1;
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) {
+      const u64 b = __ballot(q == qq);
+      if (q == qq) dst[o[qq] + __popcll(b & below)] = key;
+      o[qq] += __popcll(b);
+    }
+  }
+  __syncthreads();  // wc is reused by the next large node
+  return make_uint4((unsigned)tot[0], (unsigned)tot[1], (unsigned)tot[2], (unsigned)tot[3]);
+}
+
+
 // divide the keys of the listed nodes (list positions idx[k], or k itself when idx == nullptr)
-__device__ void partition_nodes(const QShared &S, const unsigned short *idx, int count) {
+template <class KT>
+__device__ __forceinline__ void partition_nodes(const QShared &S, KT *keys0, KT *keys1, const unsigned short *idx, int count) {
   const int wave = threadIdx.x >> 6;
+  // very large nodes (the first rounds of a big level): the whole workgroup, one node after the other
+  for (int k = 0; k < count; k++) {
+    const int i = idx ? idx[k] : k;
+    const QNode P = S.cur[i];
+    const int cnt = (int)(P.cnt & 0x7fffffffu);
+    if (cnt <= QT_BIG) continue;  // uniform: every thread reads the same node
+    const int b = (int)(P.cnt >> 31);
+    int mx, my;
+    node_mid(P, mx, my);
+    const uint4 c = partition_block<KT>(b ? keys1 : keys0, b ? keys0 : keys1, (int)P.beg, cnt, mx, my);
+    if (threadIdx.x == 0) S.qc[i] = c;
+  }
   // large nodes: one wave each
   for (int k = wave; k < count; k += QT_WAVES) {
     const int i = idx ? idx[k] : k;
     const QNode P = S.cur[i];
     const int cnt = (int)(P.cnt & 0x7fffffffu);
-    if (cnt <= QT_SMALL) continue;
+    if (cnt <= QT_SMALL || cnt > QT_BIG) continue;
     const int b = (int)(P.cnt >> 31);
     int mx, my;
     node_mid(P, mx, my);
-    const uint4 c = partition_wave(S.keys[b], S.keys[b ^ 1], (int)P.beg, cnt, mx, my);
+    const uint4 c = partition_wave<KT>(b ? keys1 : keys0, b ? keys0 : keys1, (int)P.beg, cnt, mx, my);
     if ((threadIdx.x & 63) == 0) S.qc[i] = c;
   }
   // small nodes: one lane each
@@ -167,7 +244,7 @@ __device__ void partition_nodes(const QShared &S, const unsigned short *idx, int
       const int b = (int)(P.cnt >> 31);
       int mx, my;
       node_mid(P, mx, my);
-      c = partition_lane(S.keys[b], S.keys[b ^ 1], (int)P.beg, cnt, mx, my);
+      c = partition_lane<KT>(b ? keys1 : keys0, b ? keys0 : keys1, (int)P.beg, cnt, mx, my);
     }
     S.qc[i] = c;
   }
@@ -222,74 +299,35 @@ struct QtArgs {
   int nini[ORBGPU_MAX_LEVELS];
 };
 
-__global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ u64 wsum[QT_WAVES];
-  __shared__ int s_misc[8];
-  const int l = blockIdx.x, f = blockIdx.y;
-  const LevelGeom L = g.lv[l];
+// Everything after the candidate count is known.  IN_LDS decides at compile time where the two key buffers live, so
+// that the partition loops use LDS instructions: with a run-time choice the pointers are generic and every key access
+// becomes a flat load / store (measured: 0.5-1 microsecond per dependent step).
+template <bool IN_LDS>
+__device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, const LevelGeom &L, const int l, const int f,
+                                       const int n, QShared S, unsigned *lds_keys, u64 *wsum, int *s_misc,
+                                       const CellEntry *cells, const int *cpre) {
   const int cap = a.node_cap;
   const int nF = a.budget[l];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  // carve the dynamic LDS
-  QShared S;
-  unsigned char *p = smem;
-  unsigned *lds_keys = reinterpret_cast<unsigned *>(p); p += sizeof(unsigned) * 2 * QT_LDS_KEYS;
-  QNode *nodes0 = reinterpret_cast<QNode *>(p); p += sizeof(QNode) * cap;
-  QNode *nodes1 = reinterpret_cast<QNode *>(p); p += sizeof(QNode) * cap;
-  S.qc = reinterpret_cast<uint4 *>(p); p += sizeof(uint4) * cap;
-  S.pre = reinterpret_cast<u64 *>(p); p += sizeof(u64) * cap;
-  S.pre2 = reinterpret_cast<u64 *>(p); p += sizeof(u64) * cap;
-  S.vs = reinterpret_cast<unsigned short *>(p); p += sizeof(unsigned short) * cap;
-  S.vs_new = reinterpret_cast<unsigned short *>(p); p += sizeof(unsigned short) * cap;
-  S.ord = reinterpret_cast<unsigned short *>(p); p += sizeof(unsigned short) * cap;
-  S.flag = p;
-  S.cur = nodes0;
-  S.nxt = nodes1;
-
-  // ---- gather the candidates in reference order: cells row-major, raster order inside a cell (:244-276) ----
   const int n_cells = L.ncols * L.nrows;
-  const CellEntry *cells = a.cells + (size_t)f * g.cells_per_frame + L.cell_off;
-  int *cpre = a.cell_prefix + (size_t)f * g.cells_per_frame + L.cell_off;
-  int n = 0;
-  {
-    int carry = 0;
-    for (int base = 0; base < n_cells; base += QT_THREADS) {
-      const int i = base + tid;
-      const int v = i < n_cells ? cells[i].count : 0;
-      int incl = v;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-      }
-      if (lane == 63) wsum[wave] = (u64)incl;
-      __syncthreads();
-      int woff = 0, tot = 0;
-#pragma unroll
-      for (int w = 0; w < QT_WAVES; w++) {
-        const int s = (int)wsum[w];
-        if (w < wave) woff += s;
-        tot += s;
-      }
-      if (i < n_cells) cpre[i] = carry + woff + incl - v;
-      carry += tot;
-      __syncthreads();
-    }
-    n = carry;
-  }
-  const bool in_lds = n <= QT_LDS_KEYS;
   const size_t goff = (size_t)f * g.cands_per_frame + L.cand_off;
-  S.keys[0] = in_lds ? lds_keys : a.buf_a + goff;
-  S.keys[1] = in_lds ? lds_keys + QT_LDS_KEYS : a.buf_b + goff;
+  using KT = typename std::conditional<IN_LDS, lds_u32, glb_u32>::type;
+  KT *keys0 = (KT *)(IN_LDS ? lds_keys : a.buf_a + goff);
+  KT *keys1 = (KT *)(IN_LDS ? lds_keys + QT_LDS_KEYS : a.buf_b + goff);
   {
     const unsigned *pool = a.cands + goff;
-    unsigned *dst = S.keys[0];
+    KT *dst = keys0;
     for (int c = tid; c < n_cells; c += QT_THREADS) {
       const CellEntry ce = cells[c];
       const int o = cpre[c];
-      for (int k = 0; k < ce.count; k++) dst[o + k] = pool[ce.off + k];
+      for (int k = 0; k < ce.count; k += 4) {  // four independent loads in flight
+        unsigned v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = k + u < ce.count ? pool[ce.off + k + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (k + u < ce.count) dst[o + k + u] = v[u];
+      }
     }
   }
   __syncthreads();
@@ -317,11 +355,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a)
         for (int k0 = 0; k0 < n; k0 += 64) {
           const int k = k0 + lane;
           const bool ok = k < n;
-          const unsigned key = ok ? S.keys[0][k] : 0u;
+          const unsigned key = ok ? keys0[k] : 0u;
           int bk = ok ? (int)__fdiv_rn((float)key_x(key), hX) : -1;
           if (ok) bk = min(max(bk, 0), nIni - 1);
           const u64 m = __ballot(bk == b);
-          if (bk == b) S.keys[1][o + __popcll(m & below)] = key;
+          if (bk == b) keys1[o + __popcll(m & below)] = key;
           o += __popcll(m);
         }
         if (o > beg) {  // empty roots are erased (:343-344)
@@ -349,7 +387,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a)
   int n_vs = 0;
   while (!finish && !phase2) {
     const int prevSize = Sz;
-    partition_nodes(S, nullptr, Sz);
+    partition_nodes<KT>(S, keys0, keys1, nullptr, Sz);
     __syncthreads();
     for (int i = tid; i < Sz; i += QT_THREADS) {
       const unsigned cnt = S.cur[i].cnt & 0x7fffffffu;
@@ -384,13 +422,19 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a)
     const int prevSize = Sz;
     const int m = n_vs;
     if (m == 0) break;  // nothing left to divide: size == prevSize (:477)
-    partition_nodes(S, S.vs, m);
+    partition_nodes<KT>(S, keys0, keys1, S.vs, m);
     // processing order: descending (size, creation order); rank by counting
+    // (sizes first gathered into a flat LDS array -- pre2 is free here -- so the O(m^2) count reads one broadcast
+    // word per step instead of chasing vs -> node -> cnt)
+    unsigned *sz = reinterpret_cast<unsigned *>(S.pre2);
+    for (int k = tid; k < m; k += QT_THREADS) sz[k] = S.cur[S.vs[k]].cnt & 0x7fffffffu;
+    __syncthreads();
     for (int k = tid; k < m; k += QT_THREADS) {
-      const unsigned ck = S.cur[S.vs[k]].cnt & 0x7fffffffu;
+      const unsigned ck = sz[k];
       int rank = 0;
+#pragma unroll 8
       for (int k2 = 0; k2 < m; k2++) {
-        const unsigned c2 = S.cur[S.vs[k2]].cnt & 0x7fffffffu;
+        const unsigned c2 = sz[k2];
         rank += (c2 > ck) || (c2 == ck && k2 > k);
       }
       S.ord[rank] = (unsigned short)k;
@@ -455,9 +499,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a)
   }
   for (int i = tid; i < Sz; i += QT_THREADS) {
     const QNode P = S.cur[i];
-    const unsigned *keys = S.keys[P.cnt >> 31];
+    const KT *keys = (P.cnt >> 31) ? keys1 : keys0;
     const int cnt = (int)(P.cnt & 0x7fffffffu);
     unsigned best = keys[P.beg];
+#pragma unroll 4
     for (int k = 1; k < cnt; k++) {
       const unsigned key = keys[P.beg + k];
       if (key_resp(key) > key_resp(best)) best = key;
@@ -465,6 +510,66 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a)
     out[i] = make_short2((short)(key_x(best) + ORB_MIN_BORDER), (short)(key_y(best) + ORB_MIN_BORDER));
   }
   if (tid == 0) a.kp_count[f * g.levels + l] = Sz;
+}
+
+__global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ u64 wsum[QT_WAVES];
+  __shared__ int s_misc[8];
+  const int l = blockIdx.x, f = blockIdx.y;
+  const LevelGeom L = g.lv[l];
+  const int cap = a.node_cap;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // carve the dynamic LDS
+  QShared S;
+  unsigned char *p = smem;
+  unsigned *lds_keys = reinterpret_cast<unsigned *>(p); p += sizeof(unsigned) * 2 * QT_LDS_KEYS;
+  QNode *nodes0 = reinterpret_cast<QNode *>(p); p += sizeof(QNode) * cap;
+  QNode *nodes1 = reinterpret_cast<QNode *>(p); p += sizeof(QNode) * cap;
+  S.qc = reinterpret_cast<uint4 *>(p); p += sizeof(uint4) * cap;
+  S.pre = reinterpret_cast<u64 *>(p); p += sizeof(u64) * cap;
+  S.pre2 = reinterpret_cast<u64 *>(p); p += sizeof(u64) * cap;
+  S.vs = reinterpret_cast<unsigned short *>(p); p += sizeof(unsigned short) * cap;
+  S.vs_new = reinterpret_cast<unsigned short *>(p); p += sizeof(unsigned short) * cap;
+  S.ord = reinterpret_cast<unsigned short *>(p); p += sizeof(unsigned short) * cap;
+  S.flag = p;
+  S.cur = nodes0;
+  S.nxt = nodes1;
+
+  // ---- gather the candidates in reference order: cells row-major, raster order inside a cell (:244-276) ----
+  const int n_cells = L.ncols * L.nrows;
+  const CellEntry *cells = a.cells + (size_t)f * g.cells_per_frame + L.cell_off;
+  int *cpre = a.cell_prefix + (size_t)f * g.cells_per_frame + L.cell_off;
+  int n = 0;
+  {
+    int carry = 0;
+    for (int base = 0; base < n_cells; base += QT_THREADS) {
+      const int i = base + tid;
+      const int v = i < n_cells ? cells[i].count : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) wsum[wave] = (u64)incl;
+      __syncthreads();
+      int woff = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < QT_WAVES; w++) {
+        const int s = (int)wsum[w];
+        if (w < wave) woff += s;
+        tot += s;
+      }
+      if (i < n_cells) cpre[i] = carry + woff + incl - v;
+      carry += tot;
+      __syncthreads();
+    }
+    n = carry;
+  }
+  if (n <= QT_LDS_KEYS) qt_run<true>(g, a, L, l, f, n, S, lds_keys, wsum, s_misc, cells, cpre);
+  else qt_run<false>(g, a, L, l, f, n, S, lds_keys, wsum, s_misc, cells, cpre);
 }
 
 }  // namespace
