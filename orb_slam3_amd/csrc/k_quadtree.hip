@@ -13,6 +13,8 @@
 //   finally (:486-501)  the first maximum-response key of each node is emitted in list order.
 // Parallel decomposition: nodes with many keys are partitioned by a whole wave (ballot prefix compaction),
 // small nodes by single lanes; list positions come from workgroup-wide prefix sums.
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "orbgpu_internal.h"
@@ -22,7 +24,7 @@ namespace {
 constexpr int QT_THREADS = 256;
 constexpr int QT_WAVES = QT_THREADS / 64;
 constexpr int QT_LDS_KEYS = 2048;   // keys per ping-pong buffer kept in LDS; larger levels use global scratch
-constexpr int QT_SMALL = 24;        // nodes up to this many keys are partitioned by one lane
+constexpr int QT_SMALL = 64;        // nodes up to this many keys are partitioned by a group of 16 lanes (4 nodes per wave)
 
 struct QNode {
   unsigned short x0, x1, y0, y1;  // UL.x, UR.x, UL.y, BR.y
@@ -84,66 +86,44 @@ __device__ __forceinline__ int quadrant(unsigned key, int mx, int my) {
   return (key_x(key) < mx ? 0 : 1) + (key_y(key) < my ? 0 : 2);  // n1 n2 / n3 n4, :637-645
 }
 
-// stable 4-way partition of src[beg, beg+cnt) into dst[beg, ...) by a whole wave; returns the quadrant counts
+// stable 4-way partition of src[beg, beg+cnt) into dst[beg, ...) by a whole wave, cnt <= QT_BIG: every lane loads its
+// (up to QT_BIG / 64) keys once, all loads in flight together, and both passes run from registers
 template <class KT>
-__device__ __forceinline__ uint4 partition_wave(const KT *src, KT *dst, int beg, int cnt, int mx, int my) {
+__device__ __forceinline__ uint4 partition_wave(const KT *__restrict__ src, KT *__restrict__ dst, int beg, int cnt, int mx, int my) {
+  constexpr int U = 8;  // QT_BIG / 64
   const int lane = threadIdx.x & 63;
   const u64 below = (1ull << lane) - 1ull;
-  int c[4] = {0, 0, 0, 0};
-#pragma unroll 4
-  for (int k0 = 0; k0 < cnt; k0 += 64) {  // unrolled: the key loads of four steps are in flight together
-    const int k = k0 + lane;
-    const bool ok = k < cnt;
-    const int q = ok ? quadrant(src[beg + k], mx, my) : -1;
+  unsigned key[U];
+  int q[U];
 #pragma unroll
-    for (int qq = 0; qq < 4; qq++) c[qq] += __popcll(__ballot(q == qq));
+  for (int u = 0; u < U; u++) {
+    const int k = 64 * u + lane;
+    key[u] = k < cnt ? src[beg + k] : 0u;
   }
-  int o[4];
-  o[0] = beg;
-  o[1] = o[0] + c[0];
-  o[2] = o[1] + c[1];
-  o[3] = o[2] + c[2];
-#pragma unroll 4
-  for (int k0 = 0; k0 < cnt; k0 += 64) {
-    const int k = k0 + lane;
-    const bool ok = k < cnt;
-    const unsigned key = ok ? src[beg + k] : 0u;
-    const int q = ok ? quadrant(key, mx, my) : -1;
+  int c[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int qq = 0; qq < 4; qq++) {
-      const u64 b = __ballot(q == qq);
-      if (q == qq) dst[o[qq] + __popcll(b & below)] = key;
-      o[qq] += __popcll(b);
+  for (int u = 0; u < U; u++) {
+    q[u] = 64 * u + lane < cnt ? quadrant(key[u], mx, my) : -1;
+    if (64 * u < cnt) {  // uniform
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) c[qq] += __popcll(__ballot(q[u] == qq));
     }
   }
-  return make_uint4((unsigned)c[0], (unsigned)c[1], (unsigned)c[2], (unsigned)c[3]);
-}
-
-// the same by one lane
-template <class KT>
-__device__ __forceinline__ uint4 partition_lane(const KT *src, KT *dst, int beg, int cnt, int mx, int my) {
-  int c[4] = {0, 0, 0, 0};
-#pragma unroll 4
-  for (int k = 0; k < cnt; k++) {
-    const int q = quadrant(src[beg + k], mx, my);
-    c[0] += q == 0; c[1] += q == 1; c[2] += q == 2; c[3] += q == 3;
-  }
   int o[4];
   o[0] = beg;
   o[1] = o[0] + c[0];
   o[2] = o[1] + c[1];
   o[3] = o[2] + c[2];
-#pragma unroll 4
-  for (int k = 0; k < cnt; k++) {
-    const unsigned key = src[beg + k];
-    const int q = quadrant(key, mx, my);
-    // o[] indexed dynamically would go to scratch; select instead
-    int p;
-    if (q == 0) p = o[0]++;
-    else if (q == 1) p = o[1]++;
-    else if (q == 2) p = o[2]++;
-    else p = o[3]++;
-    dst[p] = key;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    if (64 * u < cnt) {
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) {
+        const u64 bb = __ballot(q[u] == qq);
+        if (q[u] == qq) dst[o[qq] + __popcll(bb & below)] = key[u];
+        o[qq] += __popcll(bb);
+      }
+    }
   }
   return make_uint4((unsigned)c[0], (unsigned)c[1], (unsigned)c[2], (unsigned)c[3]);
 }
@@ -153,23 +133,31 @@ __device__ __forceinline__ void node_mid(const QNode &P, int &mx, int &my) {
   my = P.y0 + ((P.y1 - P.y0 + 1) >> 1);  // :607
 }
 
-// stable 4-way partition of a very large node by the whole workgroup: every wave takes a contiguous quarter of the
-// keys, counts its quadrants, and scatters behind the waves before it.  All threads call it together.
-constexpr int QT_BIG = 2048;
-template <class KT>
-__device__ __forceinline__ uint4 partition_block(const KT *src, KT *dst, int beg, int cnt, int mx, int my) {
+// stable partition into at most 4 classes of a very large key range by the whole workgroup: every wave takes a
+// contiguous quarter of the keys, counts its classes, and scatters behind the waves before it.  Keys are fetched four
+// wave-steps at a time so that (global) loads overlap.  classify(key) returns 0..3.  All threads call it together.
+constexpr int QT_BIG = 512;
+template <class KT, class F>
+__device__ __forceinline__ uint4 partition_block(const KT *__restrict__ src, KT *__restrict__ dst, int beg, int cnt, F classify) {
   __shared__ int wc[QT_WAVES][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const u64 below = (1ull << lane) - 1ull;
   const int chunk = (((cnt + QT_WAVES - 1) / QT_WAVES) + 63) & ~63;
   const int b0 = min(wave * chunk, cnt), b1 = min(b0 + chunk, cnt);
   int c[4] = {0, 0, 0, 0};
-#pragma unroll 4
-  for (int k0 = b0; k0 < b1; k0 += 64) {
-    const int k = k0 + lane;
-    const int q = k < b1 ? quadrant(src[beg + k], mx, my) : -1;
+  for (int k0 = b0; k0 < b1; k0 += 256) {
+    unsigned kv[4];
 #pragma unroll
-    for (int qq = 0; qq < 4; qq++) c[qq] += __popcll(__ballot(q == qq));
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + 64 * u + lane;
+      kv[u] = k < b1 ? src[beg + k] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int q = k0 + 64 * u + lane < b1 ? classify(kv[u]) : -1;
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) c[qq] += __popcll(__ballot(q == qq));
+    }
   }
   if (lane < 4) wc[wave][lane] = lane == 0 ? c[0] : lane == 1 ? c[1] : lane == 2 ? c[2] : c[3];
   __syncthreads();
@@ -187,30 +175,37 @@ __device__ __forceinline__ uint4 partition_block(const KT *src, KT *dst, int beg
   o[1] += beg + tot[0];
   o[2] += beg + tot[0] + tot[1];
   o[3] += beg + tot[0] + tot[1] + tot[2];
-#pragma unroll 4
-  for (int k0 = b0; k0 < b1; k0 += 64) {
-    const int k = k0 + lane;
-    const bool ok = k < b1;
-    const unsigned key = ok ? src[beg + k] : 0u;
-    const int q = ok ? quadrant(key, mx, my) : -1;
+  for (int k0 = b0; k0 < b1; k0 += 256) {
+    unsigned kv[4];
 #pragma unroll
-    for (int qq = 0; qq < 4; qq++) {
-      const u64 b = __ballot(q == qq);
-      if (q == qq) dst[o[qq] + __popcll(b & below)] = key;
-      o[qq] += __popcll(b);
+    for (int u = 0; u < 4; u++) {
+      const int k = k0 + 64 * u + lane;
+      kv[u] = k < b1 ? src[beg + k] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int q = k0 + 64 * u + lane < b1 ? classify(kv[u]) : -1;
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) {
+        const u64 bb = __ballot(q == qq);
+        if (q == qq) dst[o[qq] + __popcll(bb & below)] = kv[u];
+        o[qq] += __popcll(bb);
+      }
     }
   }
-  __syncthreads();  // wc is reused by the next large node
+  __syncthreads();  // wc is reused by the next call
   return make_uint4((unsigned)tot[0], (unsigned)tot[1], (unsigned)tot[2], (unsigned)tot[3]);
 }
 
 
 // divide the keys of the listed nodes (list positions idx[k], or k itself when idx == nullptr)
 template <class KT>
-__device__ __forceinline__ void partition_nodes(const QShared &S, KT *keys0, KT *keys1, const unsigned short *idx, int count) {
+// max_cnt: an upper bound of the listed nodes' key counts (lets whole size classes be skipped without scanning the list)
+__device__ __forceinline__ void partition_nodes(const QShared &S, KT *keys0, KT *keys1, const unsigned short *idx, int count,
+                                                int max_cnt) {
   const int wave = threadIdx.x >> 6;
   // very large nodes (the first rounds of a big level): the whole workgroup, one node after the other
-  for (int k = 0; k < count; k++) {
+  for (int k = 0; k < count && max_cnt > QT_BIG; k++) {
     const int i = idx ? idx[k] : k;
     const QNode P = S.cur[i];
     const int cnt = (int)(P.cnt & 0x7fffffffu);
@@ -218,11 +213,12 @@ __device__ __forceinline__ void partition_nodes(const QShared &S, KT *keys0, KT 
     const int b = (int)(P.cnt >> 31);
     int mx, my;
     node_mid(P, mx, my);
-    const uint4 c = partition_block<KT>(b ? keys1 : keys0, b ? keys0 : keys1, (int)P.beg, cnt, mx, my);
+    const uint4 c = partition_block(b ? keys1 : keys0, b ? keys0 : keys1, (int)P.beg, cnt,
+                                    [mx, my](unsigned key) { return quadrant(key, mx, my); });
     if (threadIdx.x == 0) S.qc[i] = c;
   }
   // large nodes: one wave each
-  for (int k = wave; k < count; k += QT_WAVES) {
+  for (int k = wave; k < count && max_cnt > QT_SMALL; k += QT_WAVES) {
     const int i = idx ? idx[k] : k;
     const QNode P = S.cur[i];
     const int cnt = (int)(P.cnt & 0x7fffffffu);
@@ -233,20 +229,57 @@ __device__ __forceinline__ void partition_nodes(const QShared &S, KT *keys0, KT 
     const uint4 c = partition_wave<KT>(b ? keys1 : keys0, b ? keys0 : keys1, (int)P.beg, cnt, mx, my);
     if ((threadIdx.x & 63) == 0) S.qc[i] = c;
   }
-  // small nodes: one lane each
-  for (int k = threadIdx.x; k < count; k += QT_THREADS) {
-    const int i = idx ? idx[k] : k;
-    const QNode P = S.cur[i];
-    const int cnt = (int)(P.cnt & 0x7fffffffu);
-    if (cnt > QT_SMALL) continue;
-    uint4 c = make_uint4(0, 0, 0, 0);
-    if (cnt > 1) {
-      const int b = (int)(P.cnt >> 31);
-      int mx, my;
-      node_mid(P, mx, my);
-      c = partition_lane<KT>(b ? keys1 : keys0, b ? keys0 : keys1, (int)P.beg, cnt, mx, my);
+  // small nodes (2 .. 64 keys): four at a time per wave, 16 lanes each.  A lane loads its (up to four) keys once --
+  // all loads of a node quad are in flight together, which is what matters when the keys sit in global memory -- and
+  // both passes (count, stable scatter) run from registers with wave ballots cut into 16-bit group fields.
+  {
+    const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
+    const unsigned gbelow = (1u << gl) - 1u;
+    for (int base = wave * 4; base < count; base += QT_WAVES * 4) {  // uniform per wave
+      const int k = base + grp;
+      int i = 0, cnt = 0, beg = 0, mx = 0, my = 0;
+      const KT *src = keys0;
+      KT *dst = keys1;
+      if (k < count) {
+        i = idx ? idx[k] : k;
+        const QNode P = S.cur[i];
+        cnt = (int)(P.cnt & 0x7fffffffu);
+        beg = (int)P.beg;
+        node_mid(P, mx, my);
+        if (P.cnt >> 31) { src = keys1; dst = keys0; }
+      }
+      const bool mine = k < count && cnt <= QT_SMALL;   // larger nodes were handled above
+      const int work = (mine && cnt > 1) ? cnt : 0;
+      unsigned key[QT_SMALL / 16];
+      int q[QT_SMALL / 16];
+#pragma unroll
+      for (int u = 0; u < QT_SMALL / 16; u++) {
+        const int kk = 16 * u + gl;
+        key[u] = kk < work ? src[beg + kk] : 0u;
+      }
+      int c[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < QT_SMALL / 16; u++) {
+        q[u] = 16 * u + gl < work ? quadrant(key[u], mx, my) : -1;
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) c[qq] += __popc((unsigned)(__ballot(q[u] == qq) >> (16 * grp)) & 0xffffu);
+      }
+      int o[4];
+      o[0] = beg;
+      o[1] = o[0] + c[0];
+      o[2] = o[1] + c[1];
+      o[3] = o[2] + c[2];
+#pragma unroll
+      for (int u = 0; u < QT_SMALL / 16; u++) {
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+          const unsigned gb = (unsigned)(__ballot(q[u] == qq) >> (16 * grp)) & 0xffffu;
+          if (q[u] == qq) dst[o[qq] + __popc(gb & gbelow)] = key[u];
+          o[qq] += __popc(gb);
+        }
+      }
+      if (mine && gl == 0) S.qc[i] = make_uint4((unsigned)c[0], (unsigned)c[1], (unsigned)c[2], (unsigned)c[3]);
     }
-    S.qc[i] = c;
   }
 }
 
@@ -257,7 +290,7 @@ __device__ __forceinline__ unsigned f2(u64 v) { return (unsigned)((v >> 42) & 0x
 
 // write the children of parent P (quadrant counts c) into the new list: creation index `cidx` onwards, positions
 // counted from the back of the `ct` children (push_front order); multi-key children are appended to vs_new at `midx`
-__device__ void emit_children(const QShared &S, const QNode &P, const uint4 c, int cidx, int ct, int midx) {
+__device__ void emit_children(const QShared &S, const QNode &P, const uint4 c, int cidx, int ct, int midx, int *max_child) {
   int mx, my;
   node_mid(P, mx, my);
   const unsigned nb = ((P.cnt >> 31) ^ 1u) << 31;
@@ -266,6 +299,7 @@ __device__ void emit_children(const QShared &S, const QNode &P, const uint4 c, i
   const unsigned short bx1[4] = {(unsigned short)mx, P.x1, (unsigned short)mx, P.x1};
   const unsigned short by0[4] = {P.y0, P.y0, (unsigned short)my, (unsigned short)my};
   const unsigned short by1[4] = {(unsigned short)my, (unsigned short)my, P.y1, P.y1};
+  if (max_child) atomicMax(max_child, (int)max(max(c.x, c.y), max(c.z, c.w)));
   unsigned beg = P.beg;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -294,6 +328,7 @@ struct QtArgs {
   short2 *kp_xy;               // [frame][kps_per_frame]
   int *kp_count;               // [frame][levels]
   int *error_flag;
+  unsigned long long *prof;    // ORBGPU_QT_PROFILE=1: wall-clock stamps of workgroup (level 0, frame 0), debugging aid
   int node_cap;                // LDS entries per list array
   int budget[ORBGPU_MAX_LEVELS];
   int nini[ORBGPU_MAX_LEVELS];
@@ -302,6 +337,7 @@ struct QtArgs {
 // Everything after the candidate count is known.  IN_LDS decides at compile time where the two key buffers live, so
 // that the partition loops use LDS instructions: with a run-time choice the pointers are generic and every key access
 // becomes a flat load / store (measured: 0.5-1 microsecond per dependent step).
+#define STAMP(i) do { if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[i] = wall_clock64(); } while (0)
 template <bool IN_LDS>
 __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, const LevelGeom &L, const int l, const int f,
                                        const int n, QShared S, unsigned *lds_keys, u64 *wsum, int *s_misc,
@@ -317,21 +353,32 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
   {
     const unsigned *pool = a.cands + goff;
     KT *dst = keys0;
-    for (int c = tid; c < n_cells; c += QT_THREADS) {
-      const CellEntry ce = cells[c];
-      const int o = cpre[c];
-      for (int k = 0; k < ce.count; k += 4) {  // four independent loads in flight
-        unsigned v[4];
+    // 16 lanes per cell, 16 cells per step, four steps in flight.  A cell's candidates sit in its fixed slot of the
+    // pool (cell index x slot size, k_cell_detect), so the candidate loads do not wait for the cell table
+    const int sub = tid & 15;
+    const int slot = ((L.wcell + 1) >> 1) * ((L.hcell + 1) >> 1);
+    constexpr int CS = QT_THREADS / 16;
+    for (int c0 = tid >> 4; c0 < n_cells; c0 += 4 * CS) {
+      int cnt[4], o[4];
+      unsigned v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = k + u < ce.count ? pool[ce.off + k + u] : 0u;
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u * CS;
+        const bool ok = c < n_cells;
+        cnt[u] = ok ? cells[c].count : 0;
+        o[u] = ok ? cpre[c] : 0;
+        v[u] = ok ? pool[(size_t)c * slot + sub] : 0u;
+      }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (k + u < ce.count) dst[o + k + u] = v[u];
+      for (int u = 0; u < 4; u++) {
+        if (sub < cnt[u]) dst[o[u] + sub] = v[u];
+        for (int k = 16 + sub; k < cnt[u]; k += 16) dst[o[u] + k] = pool[(size_t)(c0 + u * CS) * slot + k];  // rare
       }
     }
   }
   __syncthreads();
 
+  STAMP(2);
   // ---- root nodes (:310-347): nIni vertical strips, keys bucketed by int(x / hX), stable ----
   const int W = L.w - 2 * ORB_MIN_BORDER, H = L.h - 2 * ORB_MIN_BORDER;
   const int nIni = a.nini[l];
@@ -346,8 +393,30 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     }
     Sz = n > 0 ? 1 : 0;
   } else {
-    // wave 0 splits the keys bucket by bucket into buffer B, then the roots live in B
-    if (wave == 0) {
+    if (nIni <= 4) {
+      // the whole workgroup buckets the keys into buffer B (stable), then the roots live in B
+      const uint4 bc = partition_block(keys0, keys1, 0, n, [hX, nIni](unsigned key) {
+        return min(max((int)__fdiv_rn((float)key_x(key), hX), 0), nIni - 1);
+      });
+      if (tid == 0) {
+        const unsigned cnts[4] = {bc.x, bc.y, bc.z, bc.w};
+        int nroots = 0;
+        unsigned o = 0;
+        for (int b = 0; b < nIni; b++) {
+          if (cnts[b]) {  // empty roots are erased (:343-344)
+            QNode r;
+            r.x0 = (unsigned short)(int)__fmul_rn(hX, (float)b);
+            r.x1 = (unsigned short)(int)__fmul_rn(hX, (float)(b + 1));
+            r.y0 = 0; r.y1 = (unsigned short)H;
+            r.beg = o; r.cnt = cnts[b] | 0x80000000u;
+            S.cur[nroots++] = r;
+          }
+          o += cnts[b];
+        }
+        s_misc[0] = nroots;
+      }
+    } else if (wave == 0) {  // more than 4 roots (aspect ratio above 4.5): wave 0, bucket by bucket
+
       const u64 below = (1ull << lane) - 1ull;
       int o = 0, nroots = 0;
       for (int b = 0; b < nIni; b++) {
@@ -381,19 +450,27 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
   }
   __syncthreads();
 
+  STAMP(3);
   // ---- phase 1 ----------------------------------------------------------------------------------------
   bool finish = false;
   bool phase2 = false;
   int n_vs = 0;
+  int max_cnt = n;  // upper bound of the key count of any node of the list
   while (!finish && !phase2) {
+    if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[15]++;
     const int prevSize = Sz;
-    partition_nodes<KT>(S, keys0, keys1, nullptr, Sz);
+    const int rr_ = a.prof ? min((int)a.prof[15] - 1, 3) : 0;
+    if (a.prof) __syncthreads();
+    STAMP(16 + 4 * rr_);
+    partition_nodes<KT>(S, keys0, keys1, nullptr, Sz, max_cnt);
     __syncthreads();
+    STAMP(17 + 4 * rr_);
     for (int i = tid; i < Sz; i += QT_THREADS) {
       const unsigned cnt = S.cur[i].cnt & 0x7fffffffu;
       const uint4 c = S.qc[i];
       S.pre[i] = cnt > 1 ? pack3(n_children(c), 0, n_multi(c)) : pack3(0, 1, 0);
     }
+    if (tid == 0) s_misc[2] = 1;  // max child count of this round (the scan's barriers order it before the emit)
     __syncthreads();
     const u64 tot = block_excl_scan(S.pre, Sz, wsum);
     const int ct = (int)f0(tot), kt = (int)f1(tot), mt = (int)f2(tot);
@@ -405,7 +482,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     for (int i = tid; i < Sz; i += QT_THREADS) {
       const QNode P = S.cur[i];
       const u64 pr = S.pre[i];
-      if ((P.cnt & 0x7fffffffu) > 1) emit_children(S, P, S.qc[i], (int)f0(pr), ct, (int)f2(pr));
+      if ((P.cnt & 0x7fffffffu) > 1) emit_children(S, P, S.qc[i], (int)f0(pr), ct, (int)f2(pr), &s_misc[2]);
       else S.nxt[ct + (int)f1(pr)] = P;
     }
     __syncthreads();
@@ -413,16 +490,24 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     { unsigned short *t = S.vs; S.vs = S.vs_new; S.vs_new = t; }
     Sz = ct + kt;
     n_vs = mt;
+    max_cnt = s_misc[2];
     if (Sz >= nF || Sz == prevSize) finish = true;           // :422
     else if (Sz + n_vs * 3 > nF) phase2 = true;                // :424
   }
 
+  STAMP(4);
+  if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.prof[10] = n; a.prof[11] = Sz; a.prof[12] = n_vs; }
   // ---- phase 2 ----------------------------------------------------------------------------------------
   while (!finish && phase2) {
+    if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[14]++;
     const int prevSize = Sz;
     const int m = n_vs;
     if (m == 0) break;  // nothing left to divide: size == prevSize (:477)
-    partition_nodes<KT>(S, keys0, keys1, S.vs, m);
+    if (a.prof) __syncthreads();
+    STAMP(32);
+    partition_nodes<KT>(S, keys0, keys1, S.vs, m, max_cnt);  // nodes only shrink: the bound of phase 1 still holds
+    if (a.prof) __syncthreads();
+    STAMP(33);
     // processing order: descending (size, creation order); rank by counting
     // (sizes first gathered into a flat LDS array -- pre2 is free here -- so the O(m^2) count reads one broadcast
     // word per step instead of chasing vs -> node -> cnt)
@@ -479,7 +564,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     }
     for (int r = tid; r < nproc; r += QT_THREADS) {
       const int i = S.vs[S.ord[r]];
-      emit_children(S, S.cur[i], S.qc[i], (int)f0(S.pre[r]), ct, (int)f2(S.pre[r]));
+      emit_children(S, S.cur[i], S.qc[i], (int)f0(S.pre[r]), ct, (int)f2(S.pre[r]), nullptr);
     }
     for (int i = tid; i < Sz; i += QT_THREADS)
       if (!S.flag[i]) S.nxt[ct + (int)S.pre2[i]] = S.cur[i];
@@ -491,6 +576,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     if (Sz >= nF || Sz == prevSize) finish = true;  // :477
   }
 
+  STAMP(5);
   // ---- best point of each node: first maximum, strict > (:486-501) ----
   short2 *out = a.kp_xy + (size_t)f * g.kps_per_frame + L.kp_off;
   if (Sz > L.kp_cap) {
@@ -510,12 +596,15 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     out[i] = make_short2((short)(key_x(best) + ORB_MIN_BORDER), (short)(key_y(best) + ORB_MIN_BORDER));
   }
   if (tid == 0) a.kp_count[f * g.levels + l] = Sz;
+  STAMP(6);
+  if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[13] = Sz;
 }
 
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ u64 wsum[QT_WAVES];
   __shared__ int s_misc[8];
+  STAMP(0);
   const int l = blockIdx.x, f = blockIdx.y;
   const LevelGeom L = g.lv[l];
   const int cap = a.node_cap;
@@ -568,6 +657,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a)
     }
     n = carry;
   }
+  STAMP(1);
   if (n <= QT_LDS_KEYS) qt_run<true>(g, a, L, l, f, n, S, lds_keys, wsum, s_misc, cells, cpre);
   else qt_run<false>(g, a, L, l, f, n, S, lds_keys, wsum, s_misc, cells, cpre);
 }
@@ -605,6 +695,20 @@ int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
       return -1;
     configured = lds;
   }
+  a.prof = nullptr;
+  const bool profile = getenv("ORBGPU_QT_PROFILE") != nullptr;
+  if (profile && hipMalloc(&a.prof, 64 * 8) == hipSuccess) (void)hipMemset(a.prof, 0, 64 * 8);
   hipLaunchKernelGGL(k_quadtree, dim3(g.levels, n_frames), dim3(QT_THREADS), lds, c->stream, g, a);
+  if (a.prof) {  // debugging aid: synchronous, prints the phase times of one workgroup
+    unsigned long long h[64];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, a.prof, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "QT level0 frame0 (us): prefix %.1f gather+root %.1f phase1 %.1f phase2 %.1f best %.1f | n=%llu Sz@p2=%llu nvs=%llu final=%llu p1rounds=%llu p2sweeps=%llu\n",
+            (h[1] - h[0]) / 100.0, (h[3] - h[1]) / 100.0, (h[4] - h[3]) / 100.0, (h[5] - h[4]) / 100.0,
+            (h[6] - h[5]) / 100.0, h[10], h[11], h[12], h[13], h[15], h[14]);
+    for (int r = 0; r < 4; r++) fprintf(stderr, "   p1 round %d: partition %.1f\n", r, (h[17 + 4 * r] - h[16 + 4 * r]) / 100.0);
+    fprintf(stderr, "   p2 last sweep: partition %.1f\n", (h[33] - h[32]) / 100.0);
+    (void)hipFree(a.prof);
+  }
   return 0;
 }

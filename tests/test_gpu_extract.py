@@ -64,6 +64,7 @@ def test_extract_stage_parity(oracle, w, h, nfeat, seed):
     (640, 480, 6000, 8, 9, "rich"),      # budget above the number of candidates: every node ends as a singleton
     (480, 640, 800, 6, 10, "rich"),      # portrait
     (800, 300, 1200, 5, 11, "rich"),     # wide: nIni = 3
+    (1100, 200, 900, 3, 14, "rich"),     # very wide: nIni = 6, more roots than the block partition has classes
     (640, 480, 1000, 8, 12, "low"),      # low contrast: per-cell threshold fallback everywhere
     (640, 480, 1000, 8, 13, "noise"),    # white noise: very many candidates per cell
 ])
