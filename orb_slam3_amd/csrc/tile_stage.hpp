@@ -41,19 +41,38 @@ __device__ __forceinline__ void stage_tile(unsigned *__restrict__ tile, const ui
   constexpr int NR = (ROWS + 3) / 4;
   const int gx = x0 - 4 + 4 * lane;
   unsigned v[NR];
+  // tiles whose staged rows all lie inside the image (the common case) take a path without per-row border logic:
+  // one row pointer, advanced by 4 rows per step
+  const bool rows_inside = y0 >= 3 && y0 - 3 + ROWS <= h;  // wave-uniform
   if (!REFLECT) {
     const bool col_ok = gx >= 0 && gx < pitch;
+    if (rows_inside) {
+      const uint8_t *row = src + (size_t)(y0 - 3 + wave) * pitch + gx;
 #pragma unroll
-    for (int k = 0; k < NR; k++) {
-      const int r = wave + 4 * k;
-      const int gy = y0 - 3 + r;
-      v[k] = 0;
-      if (r < ROWS && gy >= 0 && gy < h && col_ok) v[k] = *reinterpret_cast<const unsigned *>(src + (size_t)gy * pitch + gx);
+      for (int k = 0; k < NR; k++) {
+        v[k] = 0;
+        if (wave + 4 * k < ROWS && col_ok) v[k] = *reinterpret_cast<const unsigned *>(row + (size_t)(4 * k) * pitch);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NR; k++) {
+        const int r = wave + 4 * k;
+        const int gy = y0 - 3 + r;
+        v[k] = 0;
+        if (r < ROWS && gy >= 0 && gy < h && col_ok) v[k] = *reinterpret_cast<const unsigned *>(src + (size_t)gy * pitch + gx);
+      }
     }
   } else {
     // wave-uniform: does any lane of this tile need a byte from outside [0, w)?
     const bool edge = x0 == 0 || x0 + 128 + 4 > w;
-    if (!edge) {
+    if (!edge && rows_inside) {
+      const uint8_t *row = src + (size_t)(y0 - 3 + wave) * pitch + gx;
+#pragma unroll
+      for (int k = 0; k < NR; k++) {
+        v[k] = 0;
+        if (wave + 4 * k < ROWS) v[k] = *reinterpret_cast<const unsigned *>(row + (size_t)(4 * k) * pitch);
+      }
+    } else if (!edge) {
 #pragma unroll
       for (int k = 0; k < NR; k++) {
         const int r = wave + 4 * k;
