@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--no-bruteforce", action="store_true")
     ap.add_argument("--no-allpairs", action="store_true", help="skip the keyframe all-pairs section (SURVEY 8e)")
     ap.add_argument("--keyframe-every", type=int, default=4)
+    ap.add_argument("--no-database", action="store_true", help="skip the keyframe-database query section (SURVEY 8f.4)")
     args = ap.parse_args()
 
     import torch
@@ -188,7 +189,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_fast_score", "achieved": round(fast_gbs, 2), "peak": hbm_peak,
                 "unit": "GB/s", "frac": round(fast_gbs / hbm_peak, 5), "traffic": traffic,
                 "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P * B, "traffic_source": traffic_src,
-                "limiter": "vector-ALU issue, not HBM: ~3.4e3 VALU wave-instructions per 128x32 tile at ~1 per clock per CU "
+                "limiter": "vector-ALU issue, not HBM: ~2.8e3 VALU wave-instructions per 128x32 tile at ~0.9 per clock per CU "
                            "(profiles/r1_pmc_sq.txt, profiles/r1_valu_rate.txt)"}
     # whole extraction against SURVEY 8d's per-frame figure A = 5P - px0 - px7 + 1978 N
     A = 5 * P - g.w[0] * g.h[0] - g.w[g.levels - 1] * g.h[g.levels - 1] + 1978 * NF
@@ -225,6 +226,41 @@ def main():
                     "frac_of_measured_peak": round(n * n / bf / peak_measured, 4),
                     "frac_of_nominal_peak": round(n * n / bf / nominal, 4),
                     "n_matched": int((di >= 0).sum().item())}
+
+    database = {}
+    if not args.no_database:
+        # place recognition (DBoW2Database::DetectNBestCandidates' query half): one BowVector against 20,000 resident
+        # keyframe BowVectors of 800 words each out of a 100k-word vocabulary; algorithmic bytes = every (word, value)
+        # of the database read once = 12 B per entry
+        from orb_slam3_amd import _lib as L
+        import ctypes as C
+        K, WPK, VOC = 20_000, 800, 100_000
+        rng = np.random.default_rng(1239)
+        words = np.sort(rng.integers(0, VOC - WPK, (K, WPK), dtype=np.int64), axis=1) + np.arange(WPK)   # strictly ascending rows
+        vals = rng.uniform(0.1, 1.0, (K, WPK))
+        vals /= vals.sum(axis=1, keepdims=True)
+        t_w = torch.from_numpy(words.astype(np.uint32).view(np.int32).reshape(-1)).to(dev)
+        t_v = torch.from_numpy(vals.reshape(-1)).to(dev)
+        t_off = torch.arange(0, (K + 1) * WPK, WPK, dtype=torch.int64, device=dev)
+        t_qw, t_qv = t_w[:WPK].clone(), t_v[:WPK].clone()
+        t_sh = torch.zeros(K, dtype=torch.int64, device=dev)
+        t_sc = torch.zeros(K, dtype=torch.float64, device=dev)
+        a = L.BowScoreArgs(t_qw.data_ptr(), t_qv.data_ptr(), None, WPK, K, t_off.data_ptr(), t_w.data_ptr(), t_v.data_ptr(),
+                           None, 0, 0)
+        times = []
+        for it in range(6):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            check(lib.orbgpu_bow_score_device(fe.handle, C.byref(a), t_sh.data_ptr(), t_sc.data_ptr()))
+            check(lib.orbgpu_synchronize(fe.handle))
+            times.append(time.perf_counter() - t1)
+        q_s = min(times[1:])
+        db_bytes = K * WPK * 12
+        database = {"keyframes": K, "words_per_keyframe": WPK, "query_ms": round(q_s * 1e3, 4),
+                    "keyframes_per_s": round(K / q_s, 1), "achieved_GBps": round(db_bytes / q_s / 1e9, 2),
+                    "frac_of_8TBps": round(db_bytes / q_s / 1e9 / hbm_peak, 5),
+                    "self_score": float(t_sc[0].item()), "self_shared_words": int(t_sh[0].item()),
+                    "includes": "launch + stream synchronisation (host clock), database resident in HBM"}
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
@@ -267,7 +303,7 @@ def main():
                       "link_matches_mean": round(float(n_matches.mean()), 1) if n_pairs else 0.0,
                       "parallelism": f"frame-sharded x{world}"},
            "roofline": roofline, "pipeline": pipeline, "matching": matching, "keyframe_allpairs": allpairs,
-           "cpu_baseline": cpu}
+           "keyframe_database": database, "cpu_baseline": cpu}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

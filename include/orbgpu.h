@@ -285,6 +285,60 @@ int orbgpu_bow_transform(orbgpu_ctx *ctx, const orbgpu_vocab *vocab, const uint8
 int orbgpu_bow_transform_device(orbgpu_ctx *ctx, const orbgpu_vocab *vocab, const uint8_t *d_desc, int32_t n,
                                 int32_t levelsup, uint32_t *d_word_id_out, uint32_t *d_node_id_out);
 
+/* ---- keyframe database (place recognition) --------------------------------------------------------- */
+/* replaces: DBoW2Database::SearchWordSharingKeyFrames (frame/database/DBoW2/dbo_w2_database.cpp:83-103) and the
+ * vocabulary->score(query BowVector, keyframe BowVector) calls of FilterCandidatesByWordSharingAcceptableScore
+ * (:114-132) = {L1,L2,ChiSquare,Bhattacharyya,DotProduct}Scoring::score (DBoW2/DBoW2/ScoringObject.cpp:23-120,
+ * :125-170, :226-311), for ONE query against ALL keyframes of the database in one call.
+ * The database is passed keyframe-major (the transpose of inverted_file_, dbo_w2_database.h:55): the words of
+ * keyframe k are entries kf_offsets[k] .. kf_offsets[k+1]) of kf_words (strictly ascending inside a keyframe, the
+ * std::map order of its BowVector), kf_values their WordValue, kf_counts the inverted-file value of (word,
+ * keyframe) (= DBoW2Handler::GetWordFrequencies, dbo_w2_handler.cpp:90-92; NULL = all 1).  The query is given the
+ * same way (q_words strictly ascending).
+ * shared_words[k] = sum over common words of kf_count * q_count (0 = the keyframe is not in the reference's
+ * WordSharingKeyFrameMap); score[k] = score(query, keyframe k), accumulated in word order, bit-exact in double
+ * (the reference evaluates it only where shared_words passes the 0.8 * max cut; here every keyframe gets one).
+ * scoring = DBoW2::ScoringType (BowVector.h): 0 L1_NORM, 1 L2_NORM, 2 CHI_SQUARE, 4 BHATTACHARYYA, 5 DOT_PRODUCT;
+ * 3 (KL) is rejected with ORBGPU_E_INVALID. */
+typedef struct {
+  const uint32_t *q_words;
+  const double *q_values;
+  const uint32_t *q_counts;
+  int32_t n_q;
+  int32_t n_keyframes;
+  const int64_t *kf_offsets;
+  const uint32_t *kf_words;
+  const double *kf_values;
+  const uint32_t *kf_counts;
+  int32_t scoring;
+  int32_t reserved;
+} orbgpu_bow_score_args;
+int orbgpu_bow_score(orbgpu_ctx *ctx, const orbgpu_bow_score_args *args, uint64_t *shared_words, double *score);
+/* device form: every pointer of the struct and both outputs are device pointers (a database that stays resident
+ * between queries); asynchronous on the context's stream; the orderings are the caller's responsibility. */
+int orbgpu_bow_score_device(orbgpu_ctx *ctx, const orbgpu_bow_score_args *device_args, uint64_t *d_shared_words,
+                            double *d_score);
+
+/* A database that stays resident on the device between queries -- what IKeyFrameDatabase
+ * (frame/database/ikey_frame_database.h:14-29) is to its callers: Append (dbo_w2_database.cpp:53-61), Erase
+ * (:187-195) and the query part of DetectNBestCandidates (:63-81).  A keyframe is named by a caller-chosen 64-bit id
+ * (KeyFrame::Id(), the value Serialize writes, :46).  words / values = the keyframe's BowVector in std::map order
+ * (strictly ascending), counts = its word frequencies (NULL = 1 per word; a database created with with_counts = 0
+ * stores none and accepts only NULL).  Appending an id that is present replaces its entry.  Erasing an absent id is
+ * not an error (the reference's map::erase is a no-op).  The handle must be destroyed before its context. */
+typedef struct orbgpu_bowdb orbgpu_bowdb;
+int orbgpu_bowdb_create(orbgpu_ctx *ctx, int32_t scoring, int32_t with_counts, orbgpu_bowdb **out);
+void orbgpu_bowdb_destroy(orbgpu_bowdb *db);
+int orbgpu_bowdb_append(orbgpu_bowdb *db, uint64_t keyframe_id, const uint32_t *words, const double *values,
+                        const uint32_t *counts, int32_t n_words);
+int orbgpu_bowdb_erase(orbgpu_bowdb *db, uint64_t keyframe_id);
+int orbgpu_bowdb_size(const orbgpu_bowdb *db, int32_t *n_keyframes);
+/* One query against every resident keyframe (host pointers): keyframe_ids / shared_words / score receive
+ * *n_out <= capacity entries in the database's internal order; ORBGPU_E_CAPACITY when capacity < size. */
+int orbgpu_bowdb_query(orbgpu_bowdb *db, const uint32_t *q_words, const double *q_values, const uint32_t *q_counts,
+                       int32_t n_q, int32_t capacity, uint64_t *keyframe_ids, uint64_t *shared_words, double *score,
+                       int32_t *n_out);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-stage GPU time in milliseconds (HIP events on the context's stream), averaged over the extract calls
  * enqueued since the last orbgpu_synchronize / orbgpu_stage_times (at most the last 32); waits for the stream.

@@ -1275,3 +1275,89 @@ unsigned oo_predict_scale(double distance, double max_distance, double scale_fac
   if (scale >= (unsigned)levels) scale = (unsigned)levels - 1;
   return scale;
 }
+
+/* ---- keyframe database ------------------------------------------------------------------------------------ */
+/* std::map<WordId, WordValue>::lower_bound on an ascending array */
+static int bow_lower_bound(const uint32_t *words, int n, uint32_t key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = lo + (hi - lo) / 2;
+    if (words[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+/* {L1,L2,ChiSquare,Bhattacharyya,DotProduct}Scoring::score, DBoW2/DBoW2/ScoringObject.cpp */
+static double bow_vector_score(const uint32_t *w1, const double *v1, int n1, const uint32_t *w2, const double *v2, int n2,
+                               int scoring) {
+  int i1 = 0, i2 = 0;
+  double score = 0;
+  while (i1 != n1 && i2 != n2) {
+    const double vi = v1[i1], wi = v2[i2];
+    if (w1[i1] == w2[i2]) {
+      switch (scoring) {
+        case 0: score += fabs(vi - wi) - fabs(vi) - fabs(wi); break; /* :41 */
+        case 1: score += vi * wi; break;                              /* :91 */
+        case 2: if (vi + wi != 0.0) score += vi * wi / (vi + wi); break; /* :148 */
+        case 4: score += sqrt(vi * wi); break;                        /* :245 */
+        case 5: score += vi * wi; break;                              /* :290 */
+        default: return NAN;
+      }
+      ++i1;
+      ++i2;
+    } else if (w1[i1] < w2[i2]) {
+      i1 = bow_lower_bound(w1, n1, w2[i2]); /* v1.lower_bound(v2_it->first) */
+    } else {
+      i2 = bow_lower_bound(w2, n2, w1[i1]);
+    }
+  }
+  switch (scoring) {
+    case 0: score = -score / 2.0; break; /* :65 */
+    case 1:
+      if (score >= 1) score = 1.0; /* :114-117 */
+      else score = 1.0 - sqrt(1.0 - score);
+      break;
+    case 2: score = 2. * score; break; /* :167 */
+    default: break;
+  }
+  return score;
+}
+
+typedef struct { uint32_t word; int32_t kf; uint32_t count; } inv_entry;
+static int cmp_inv_entry(const void *a, const void *b) {
+  const inv_entry *x = (const inv_entry *)a, *y = (const inv_entry *)b;
+  if (x->word != y->word) return x->word < y->word ? -1 : 1;
+  return (x->kf > y->kf) - (x->kf < y->kf);
+}
+
+void oo_bow_score(const uint32_t *q_words, const double *q_values, const uint32_t *q_counts, int n_q,
+                  const int64_t *kf_off, const uint32_t *kf_words, const double *kf_values, const uint32_t *kf_counts,
+                  int n_kf, int scoring, uint64_t *shared_words, double *score) {
+  /* Append, :53-61: inverted_file_[word][keyframe] = count.  Held as one array sorted by (word, keyframe); the
+   * reference's inner maps are ordered by KeyFrame* (allocator dependent), which no integer sum depends on. */
+  const int64_t total = n_kf > 0 ? kf_off[n_kf] : 0;
+  inv_entry *inv = (inv_entry *)malloc(sizeof(inv_entry) * (size_t)(total > 0 ? total : 1));
+  for (int k = 0; k < n_kf; k++)
+    for (int64_t i = kf_off[k]; i < kf_off[k + 1]; i++) {
+      inv[i].word = kf_words[i];
+      inv[i].kf = k;
+      inv[i].count = kf_counts ? kf_counts[i] : 1u;
+    }
+  qsort(inv, (size_t)total, sizeof(inv_entry), cmp_inv_entry);
+  /* SearchWordSharingKeyFrames, :96-102 */
+  for (int k = 0; k < n_kf; k++) shared_words[k] = 0;
+  for (int b = 0; b < n_q; b++) {
+    int64_t lo = 0, hi = total; /* first entry of inverted_file_[b.first] */
+    while (lo < hi) {
+      const int64_t mid = lo + (hi - lo) / 2;
+      if (inv[mid].word < q_words[b]) lo = mid + 1; else hi = mid;
+    }
+    for (int64_t e = lo; e < total && inv[e].word == q_words[b]; e++)
+      shared_words[inv[e].kf] += (uint64_t)inv[e].count * (uint64_t)(q_counts ? q_counts[b] : 1u);
+  }
+  free(inv);
+  /* :127-128, for every keyframe */
+  for (int k = 0; k < n_kf; k++)
+    score[k] = bow_vector_score(q_words, q_values, n_q, kf_words + kf_off[k], kf_values + kf_off[k],
+                                (int)(kf_off[k + 1] - kf_off[k]), scoring);
+}

@@ -193,6 +193,17 @@ int oo_match_bow(const uint8_t *desc_to, int n_to, const uint8_t *desc_from, int
                  const int32_t *from_off, const uint32_t *from_ids, int n_from_nodes, unsigned threshold, double ratio,
                  int32_t *match_from, uint32_t *match_dist);
 
+/* Keyframe-database query.  The database is passed keyframe by keyframe (words of keyframe k = entries kf_off[k] ..
+ * kf_off[k+1]), ascending), exactly what DBoW2Database::Append receives per keyframe; the function first builds the
+ * inverted file as Append does (frame/database/DBoW2/dbo_w2_database.cpp:53-61: inverted_file_[word][keyframe] =
+ * count), then runs SearchWordSharingKeyFrames (:83-103) over the query's word frequencies and, for every keyframe,
+ * vocabulary->score(query, keyframe) as FilterCandidatesByWordSharingAcceptableScore calls it (:127-128), restating
+ * DBoW2/DBoW2/ScoringObject.cpp (L1 :23-68, L2 :73-120, chi-square :125-170, Bhattacharyya :226-266, dot product
+ * :271-311; scoring = DBoW2::ScoringType, KL = 3 is not restated and yields NaN).  counts may be NULL (= 1). */
+void oo_bow_score(const uint32_t *q_words, const double *q_values, const uint32_t *q_counts, int n_q,
+                  const int64_t *kf_off, const uint32_t *kf_words, const double *kf_values, const uint32_t *kf_counts,
+                  int n_kf, int scoring, uint64_t *shared_words, double *score);
+
 /* OrientationValidator::Validate validators/orientation_validator.cpp:16-97.
  * match_from[i] >= 0 are the matches (to i -> from match_from[i]); discarded ones are set to -1.
  * returns number discarded. */

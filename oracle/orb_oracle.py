@@ -335,3 +335,21 @@ def orientation_validate(angle_to, angle_from, match_from):
 
 def predict_scale(distance, max_distance, scale_factor, levels):
     return int(lib().oo_predict_scale(distance, max_distance, scale_factor, levels))
+
+
+def bow_score(q_words, q_values, kf_offsets, kf_words, kf_values, scoring=0, q_counts=None, kf_counts=None):
+    """-> (shared word counts u64[n_kf], scores f64[n_kf]); see oo_bow_score."""
+    q_words = np.ascontiguousarray(q_words, np.uint32)
+    q_values = np.ascontiguousarray(q_values, np.float64)
+    kf_offsets = np.ascontiguousarray(kf_offsets, np.int64)
+    kf_words = np.ascontiguousarray(kf_words, np.uint32)
+    kf_values = np.ascontiguousarray(kf_values, np.float64)
+    qc = None if q_counts is None else np.ascontiguousarray(q_counts, np.uint32)
+    kc = None if kf_counts is None else np.ascontiguousarray(kf_counts, np.uint32)
+    n_kf = len(kf_offsets) - 1
+    shared = np.zeros(max(n_kf, 1), np.uint64)
+    score = np.zeros(max(n_kf, 1), np.float64)
+    lib().oo_bow_score(_p(q_words), _p(q_values), _p(qc) if qc is not None else None, len(q_words), _p(kf_offsets),
+                       _p(kf_words), _p(kf_values), _p(kc) if kc is not None else None, n_kf, int(scoring), _p(shared),
+                       _p(score))
+    return shared[:n_kf], score[:n_kf]

@@ -54,6 +54,12 @@ class GroupArgs(C.Structure):
                 ("from_ids", C.c_void_p), ("threshold", C.c_uint32), ("ratio", C.c_double)]
 
 
+class BowScoreArgs(C.Structure):
+    _fields_ = [("q_words", C.c_void_p), ("q_values", C.c_void_p), ("q_counts", C.c_void_p), ("n_q", C.c_int32),
+                ("n_keyframes", C.c_int32), ("kf_offsets", C.c_void_p), ("kf_words", C.c_void_p), ("kf_values", C.c_void_p),
+                ("kf_counts", C.c_void_p), ("scoring", C.c_int32), ("reserved", C.c_int32)]
+
+
 KP_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("angle", "<f4"), ("size", "<i4"), ("level", "<i4"), ("reserved", "<i4")])
 assert KP_DTYPE.itemsize == 32
 
@@ -64,7 +70,9 @@ EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_g
            "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
            "orbgpu_match_allpairs_device", "orbgpu_vocab_create", "orbgpu_vocab_destroy", "orbgpu_bow_transform",
            "orbgpu_bow_transform_device", "orbgpu_distinctive_descriptor", "orbgpu_distinctive_descriptor_device",
-           "orbgpu_keypoint_geometry", "orbgpu_keypoint_geometry_device",
+           "orbgpu_keypoint_geometry", "orbgpu_keypoint_geometry_device", "orbgpu_bow_score", "orbgpu_bow_score_device",
+           "orbgpu_bowdb_create", "orbgpu_bowdb_destroy", "orbgpu_bowdb_append", "orbgpu_bowdb_erase", "orbgpu_bowdb_size",
+           "orbgpu_bowdb_query",
            "orbgpu_rotation_filter", "orbgpu_stage_times",
            "orbgpu_popcount_peak"]
 
@@ -108,6 +116,14 @@ def load():
         "orbgpu_vocab_destroy": (None, [vp]),
         "orbgpu_bow_transform": (i32, [vp, vp, vp, i32, i32, vp, vp]),
         "orbgpu_bow_transform_device": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+        "orbgpu_bow_score": (i32, [vp, C.POINTER(BowScoreArgs), vp, vp]),
+        "orbgpu_bow_score_device": (i32, [vp, C.POINTER(BowScoreArgs), vp, vp]),
+        "orbgpu_bowdb_create": (i32, [vp, i32, i32, C.POINTER(vp)]),
+        "orbgpu_bowdb_destroy": (None, [vp]),
+        "orbgpu_bowdb_append": (i32, [vp, u64, vp, vp, vp, i32]),
+        "orbgpu_bowdb_erase": (i32, [vp, u64]),
+        "orbgpu_bowdb_size": (i32, [vp, C.POINTER(i32)]),
+        "orbgpu_bowdb_query": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, C.POINTER(i32)]),
         "orbgpu_rotation_filter": (i32, [vp, vp, i32, vp, i32, vp, C.POINTER(i32)]),
         "orbgpu_stage_times": (i32, [vp, vp]),
         "orbgpu_popcount_peak": (i32, [vp, C.POINTER(dbl)]),

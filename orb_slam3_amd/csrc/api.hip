@@ -999,6 +999,291 @@ int orbgpu_bow_transform(orbgpu_ctx *ctx, const orbgpu_vocab *vocab, const uint8
   return ORBGPU_OK;
 }
 
+int orbgpu_bow_score_device(orbgpu_ctx *ctx, const orbgpu_bow_score_args *a, uint64_t *d_shared_words, double *d_score) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_q < 0 || a->n_keyframes < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (a->scoring < 0 || a->scoring > 5 || a->scoring == 3)
+    return fail(ctx, ORBGPU_E_INVALID, "scoring must be L1_NORM, L2_NORM, CHI_SQUARE, BHATTACHARYYA or DOT_PRODUCT");
+  if (a->n_keyframes == 0) return ORBGPU_OK;
+  if (!a->kf_offsets || !d_shared_words || !d_score || (a->n_q > 0 && (!a->q_words || !a->q_values)))
+    return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  BowScoreDev d{a->q_words, a->q_values, a->q_counts, a->n_q, a->n_keyframes,
+                reinterpret_cast<const long long *>(a->kf_offsets), reinterpret_cast<const long long *>(a->kf_offsets) + 1,
+                a->kf_words, a->kf_values, a->kf_counts, a->scoring};
+  launch_bow_score(ctx, d, reinterpret_cast<unsigned long long *>(d_shared_words), d_score);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
+int orbgpu_bow_score(orbgpu_ctx *ctx, const orbgpu_bow_score_args *a, uint64_t *shared_words, double *score) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_q < 0 || a->n_keyframes < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (a->n_keyframes == 0) return ORBGPU_OK;
+  if (!a->kf_offsets || !shared_words || !score || (a->n_q > 0 && (!a->q_words || !a->q_values)))
+    return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  for (int i = 1; i < a->n_q; i++)
+    if (a->q_words[i] <= a->q_words[i - 1]) return fail(ctx, ORBGPU_E_INVALID, "query words must be strictly ascending");
+  if (a->kf_offsets[0] != 0) return fail(ctx, ORBGPU_E_INVALID, "offsets must start at 0");
+  for (int k = 0; k < a->n_keyframes; k++) {
+    if (a->kf_offsets[k + 1] < a->kf_offsets[k]) return fail(ctx, ORBGPU_E_INVALID, "offsets must be non-decreasing");
+    if (a->kf_offsets[k + 1] > a->kf_offsets[k] && (!a->kf_words || !a->kf_values)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+    for (int64_t i = a->kf_offsets[k] + 1; i < a->kf_offsets[k + 1]; i++)
+      if (a->kf_words[i] <= a->kf_words[i - 1])
+        return fail(ctx, ORBGPU_E_INVALID, "keyframe words must be strictly ascending inside a keyframe");
+  }
+  const size_t total = (size_t)a->kf_offsets[a->n_keyframes], nq = (size_t)a->n_q, nk = (size_t)a->n_keyframes;
+  Staging st{ctx};
+  orbgpu_bow_score_args d = *a;
+  unsigned long long *d_shared;
+  double *d_score;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = st.reserve(pad256(nq * 4) * 2 + pad256(nq * 8) + pad256((nk + 1) * 8) + pad256(total * 4) * 2 + pad256(total * 8) +
+                        2 * pad256(nk * 8) + 4096);
+    if (rc) return rc;
+    d.q_words = nq ? st.put(a->q_words, nq) : nullptr;
+    d.q_values = nq ? st.put(a->q_values, nq) : nullptr;
+    d.q_counts = (nq && a->q_counts) ? st.put(a->q_counts, nq) : nullptr;
+    d.kf_offsets = st.put(a->kf_offsets, nk + 1);
+    d.kf_words = total ? st.put(a->kf_words, total) : nullptr;
+    d.kf_values = total ? st.put(a->kf_values, total) : nullptr;
+    d.kf_counts = (total && a->kf_counts) ? st.put(a->kf_counts, total) : nullptr;
+    d_shared = st.put<unsigned long long>(nullptr, nk);
+    d_score = st.put<double>(nullptr, nk);
+  }
+  int rc = orbgpu_bow_score_device(ctx, &d, reinterpret_cast<uint64_t *>(d_shared), d_score);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(hipMemcpyAsync(shared_words, d_shared, nk * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(score, d_score, nk * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return ORBGPU_OK;
+}
+
+// ---- resident keyframe database ----------------------------------------------------------------------
+namespace {
+bool scoring_ok(int s) { return s >= 0 && s <= 5 && s != 3; }
+
+// arena for at least `need` entries; live runs are moved (and holes dropped) when it has to grow or is mostly holes
+int bowdb_reserve(orbgpu_bowdb *db, long long need) {
+  orbgpu_ctx *ctx = db->ctx;
+  const long long live = db->used - db->holes;
+  const bool grow = db->used + need > db->cap;
+  const bool squeeze = db->holes > (1 << 16) && db->holes > live;
+  if (!grow && !squeeze) return 0;
+  long long cap = db->cap;
+  if (live + need > cap / 2 || cap == 0) cap = std::max<long long>(2 * (live + need), 1 << 16);
+  unsigned *nw = nullptr, *nc = nullptr;
+  double *nv = nullptr;
+  const int n = (int)db->ids.size();
+  std::vector<long long> nbeg(n), nend(n);
+  long long pos = 0;
+  for (int k = 0; k < n; k++) {
+    nbeg[k] = pos;
+    pos += db->end[k] - db->beg[k];
+    nend[k] = pos;
+  }
+  HIP_TRY(dmalloc(&nw, (size_t)cap));
+  hipError_t e = dmalloc(&nv, (size_t)cap);
+  if (e == hipSuccess && db->with_counts) e = dmalloc(&nc, (size_t)cap);
+  long long *d_tab = nullptr;
+  if (e == hipSuccess && n) e = dmalloc(&d_tab, (size_t)3 * n);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(d_tab, db->beg.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(d_tab + n, nbeg.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n) e = hipMemcpyAsync(d_tab + 2 * n, nend.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && n) {
+    launch_bowdb_compact(ctx, n, d_tab, d_tab + n, d_tab + 2 * n, db->d_words, db->d_values, db->d_counts, nw, nv, nc);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (d_tab) (void)hipFree(d_tab);
+  if (e != hipSuccess) {
+    for (void *q : {(void *)nw, (void *)nv, (void *)nc})
+      if (q) (void)hipFree(q);
+    return fail_hip(ctx, e, "keyframe database arena", __FILE__, __LINE__);
+  }
+  for (void *q : {(void *)db->d_words, (void *)db->d_values, (void *)db->d_counts})
+    if (q) (void)hipFree(q);
+  db->d_words = nw;
+  db->d_values = nv;
+  db->d_counts = nc;
+  db->cap = cap;
+  db->beg.swap(nbeg);
+  db->end.swap(nend);
+  db->used = pos;
+  db->holes = 0;
+  db->table_dirty = true;
+  return 0;
+}
+}  // namespace
+
+int orbgpu_bowdb_create(orbgpu_ctx *ctx, int32_t scoring, int32_t with_counts, orbgpu_bowdb **out) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!out) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  *out = nullptr;
+  if (!scoring_ok(scoring))
+    return fail(ctx, ORBGPU_E_INVALID, "scoring must be L1_NORM, L2_NORM, CHI_SQUARE, BHATTACHARYYA or DOT_PRODUCT");
+  orbgpu_bowdb *db = new orbgpu_bowdb;
+  db->ctx = ctx;
+  db->scoring = scoring;
+  db->with_counts = with_counts != 0;
+  *out = db;
+  return ORBGPU_OK;
+}
+
+void orbgpu_bowdb_destroy(orbgpu_bowdb *db) {
+  if (!db) return;
+  if (db->ctx) {
+    (void)hipSetDevice(db->ctx->device);
+    (void)hipStreamSynchronize(db->ctx->stream);
+  }
+  for (void *q : {(void *)db->d_words, (void *)db->d_values, (void *)db->d_counts, (void *)db->d_beg, (void *)db->d_end,
+                  (void *)db->d_query})
+    if (q) (void)hipFree(q);
+  delete db;
+}
+
+int orbgpu_bowdb_size(const orbgpu_bowdb *db, int32_t *n_keyframes) {
+  if (!db || !n_keyframes) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(db->ctx->mu);
+  *n_keyframes = (int32_t)db->ids.size();
+  return ORBGPU_OK;
+}
+
+int orbgpu_bowdb_erase(orbgpu_bowdb *db, uint64_t keyframe_id) {
+  if (!db) return ORBGPU_E_INVALID;
+  orbgpu_ctx *ctx = db->ctx;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  auto it = db->slot_of.find(keyframe_id);
+  if (it == db->slot_of.end()) return ORBGPU_OK;
+  const int slot = it->second, last = (int)db->ids.size() - 1;
+  db->holes += db->end[slot] - db->beg[slot];
+  db->slot_of.erase(it);
+  if (slot != last) {  // the last keyframe takes the freed slot
+    db->ids[slot] = db->ids[last];
+    db->beg[slot] = db->beg[last];
+    db->end[slot] = db->end[last];
+    db->slot_of[db->ids[slot]] = slot;
+  }
+  db->ids.pop_back();
+  db->beg.pop_back();
+  db->end.pop_back();
+  db->table_dirty = true;
+  return ORBGPU_OK;
+}
+
+int orbgpu_bowdb_append(orbgpu_bowdb *db, uint64_t keyframe_id, const uint32_t *words, const double *values,
+                        const uint32_t *counts, int32_t n_words) {
+  if (!db) return ORBGPU_E_INVALID;
+  orbgpu_ctx *ctx = db->ctx;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n_words < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+    if (n_words > 0 && (!words || !values)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+    if (counts && !db->with_counts) return fail(ctx, ORBGPU_E_INVALID, "this database was created without word counts");
+    for (int i = 1; i < n_words; i++)
+      if (words[i] <= words[i - 1]) return fail(ctx, ORBGPU_E_INVALID, "keyframe words must be strictly ascending");
+  }
+  int rc = orbgpu_bowdb_erase(db, keyframe_id);  // an id that is present is replaced
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  rc = bowdb_reserve(db, n_words);
+  if (rc) return rc;
+  const long long at = db->used;
+  if (n_words) {
+    HIP_TRY(hipMemcpyAsync(db->d_words + at, words, (size_t)n_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db->d_values + at, values, (size_t)n_words * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (db->with_counts) {
+      std::vector<uint32_t> ones;
+      if (!counts) {
+        ones.assign((size_t)n_words, 1u);
+        counts = ones.data();
+      }
+      HIP_TRY(hipMemcpyAsync(db->d_counts + at, counts, (size_t)n_words * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));  // the caller's arrays may go away after the call
+    }
+  }
+  db->slot_of[keyframe_id] = (int)db->ids.size();
+  db->ids.push_back(keyframe_id);
+  db->beg.push_back(at);
+  db->end.push_back(at + n_words);
+  db->used = at + n_words;
+  db->table_dirty = true;
+  return ORBGPU_OK;
+}
+
+int orbgpu_bowdb_query(orbgpu_bowdb *db, const uint32_t *q_words, const double *q_values, const uint32_t *q_counts,
+                       int32_t n_q, int32_t capacity, uint64_t *keyframe_ids, uint64_t *shared_words, double *score,
+                       int32_t *n_out) {
+  if (!db) return ORBGPU_E_INVALID;
+  orbgpu_ctx *ctx = db->ctx;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!n_out) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  *n_out = 0;
+  if (n_q < 0 || capacity < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (n_q > 0 && (!q_words || !q_values)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  for (int i = 1; i < n_q; i++)
+    if (q_words[i] <= q_words[i - 1]) return fail(ctx, ORBGPU_E_INVALID, "query words must be strictly ascending");
+  const size_t n = db->ids.size();
+  if ((size_t)capacity < n) return fail(ctx, ORBGPU_E_CAPACITY, "output capacity below the number of keyframes");
+  if (n == 0) return ORBGPU_OK;
+  if (!keyframe_ids || !shared_words || !score) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (db->table_dirty) {
+    if (db->table_cap < n) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (db->d_beg) HIP_TRY(hipFree(db->d_beg));
+      if (db->d_end) HIP_TRY(hipFree(db->d_end));
+      db->d_beg = db->d_end = nullptr;
+      db->table_cap = 0;
+      const size_t cap = std::max<size_t>(2 * n, 1024);
+      HIP_TRY(dmalloc(&db->d_beg, cap));
+      HIP_TRY(dmalloc(&db->d_end, cap));
+      db->table_cap = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(db->d_beg, db->beg.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(db->d_end, db->end.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    db->table_dirty = false;
+  }
+  const size_t nq = (size_t)n_q;
+  const size_t o_w = 0, o_v = pad256(nq * 4), o_c = o_v + pad256(nq * 8), o_sh = o_c + pad256(nq * 4), o_sc = o_sh + pad256(n * 8),
+               bytes = o_sc + pad256(n * 8);
+  if (db->query_cap < bytes) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (db->d_query) HIP_TRY(hipFree(db->d_query));
+    db->d_query = nullptr;
+    db->query_cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&db->d_query), 2 * bytes));
+    db->query_cap = 2 * bytes;
+  }
+  char *q = db->d_query;
+  if (nq) {
+    HIP_TRY(hipMemcpyAsync(q + o_w, q_words, nq * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(q + o_v, q_values, nq * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (q_counts) HIP_TRY(hipMemcpyAsync(q + o_c, q_counts, nq * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  BowScoreDev d{reinterpret_cast<unsigned *>(q + o_w), reinterpret_cast<double *>(q + o_v),
+                q_counts ? reinterpret_cast<unsigned *>(q + o_c) : nullptr, n_q, (int)n, db->d_beg, db->d_end, db->d_words,
+                db->d_values, db->with_counts ? db->d_counts : nullptr, db->scoring};
+  launch_bow_score(ctx, d, reinterpret_cast<unsigned long long *>(q + o_sh), reinterpret_cast<double *>(q + o_sc));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(shared_words, q + o_sh, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(score, q + o_sc, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (size_t k = 0; k < n; k++) keyframe_ids[k] = db->ids[k];
+  *n_out = (int32_t)n;
+  return ORBGPU_OK;
+}
+
 int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
                                  const int32_t *d_n_rows, int32_t n_rows, const orbgpu_keypoint *d_kp_cols,
                                  const uint8_t *d_desc_cols, const int32_t *d_n_cols, int32_t n_cols, int32_t capacity,

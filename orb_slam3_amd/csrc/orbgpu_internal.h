@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/orbgpu.h"
@@ -168,6 +169,43 @@ void launch_match_groups(const orbgpu_ctx *c, const orbgpu_group_args &a, int n_
                          void *scratch);
 void launch_bow_transform(const orbgpu_ctx *c, const orbgpu_vocab *v, const uint8_t *d_desc, int n, int levelsup,
                           unsigned *d_word, unsigned *d_node);
+// keyframe BowVectors resident on the device of the context that created the database: an append-only arena of
+// (word, value[, count]) runs plus a per-keyframe (begin, end) table; erased runs become holes that a compaction
+// pass squeezes out once they outweigh the live data
+struct orbgpu_bowdb {
+  orbgpu_ctx *ctx = nullptr;
+  int scoring = 0;
+  bool with_counts = false;
+  unsigned *d_words = nullptr;
+  double *d_values = nullptr;
+  unsigned *d_counts = nullptr;
+  long long cap = 0, used = 0, holes = 0;       // arena entries
+  std::vector<unsigned long long> ids;           // slot -> keyframe id
+  std::vector<long long> beg, end;               // slot -> arena run
+  std::unordered_map<unsigned long long, int> slot_of;
+  long long *d_beg = nullptr, *d_end = nullptr;  // device copy of the table
+  size_t table_cap = 0;
+  bool table_dirty = true;
+  char *d_query = nullptr;                       // query words / values / counts and the two result arrays
+  size_t query_cap = 0;
+};
+
+// one query against keyframe-major BowVectors: the words of keyframe k are entries kf_beg[k] .. kf_end[k])
+struct BowScoreDev {
+  const unsigned *q_words;
+  const double *q_values;
+  const unsigned *q_counts;  // may be null (= 1)
+  int n_q, n_keyframes;
+  const long long *kf_beg, *kf_end;
+  const unsigned *kf_words;
+  const double *kf_values;
+  const unsigned *kf_counts;  // may be null (= 1)
+  int scoring;
+};
+void launch_bow_score(const orbgpu_ctx *c, const BowScoreDev &a, unsigned long long *d_shared, double *d_score);
+void launch_bowdb_compact(const orbgpu_ctx *c, int n_keyframes, const long long *d_old_beg, const long long *d_new_beg,
+                          const long long *d_new_end, const unsigned *w_in, const double *v_in, const unsigned *c_in,
+                          unsigned *w_out, double *v_out, unsigned *c_out);
 void launch_distinctive(const orbgpu_ctx *c, const uint8_t *d_desc, const int *d_offsets, int n_points, int *d_best);
 size_t allpairs_lds_bytes(int capacity);
 void launch_match_allpairs(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,

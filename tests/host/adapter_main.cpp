@@ -13,6 +13,7 @@
 #include "hip_bow_vocabulary.h"
 #include "hip_map_point.h"
 #include "hip_monocular_camera.h"
+#include "hip_key_frame_database.h"
 
 using namespace orb_slam3;
 
@@ -126,6 +127,22 @@ int main(int argc, char ** argv) {
   cam.k[0] = -0.28; cam.k[1] = 0.07; cam.k[2] = 2e-4; cam.k[3] = 1.8e-5; cam.k[4] = 0.0;
   const std::vector<uint8_t> geom_ok = camera::HipUndistortFeatures(hip->context(), cam, f1);
 
+  // DBoW2Database: keyframe g holds the words (j * 13) % 97 of the descriptors j = g, g + 9, ... of frame 0, value =
+  // L1-normalised byte 1 of the descriptor; keyframe 4 is erased again, keyframe 2 re-appended; query = keyframe 6's vector
+  frame::HipKeyFrameIndex index(hip->context(), 0 /* L1_NORM */);
+  std::vector<std::map<unsigned, double>> kf_bow(9);
+  for (size_t g = 0; g < kf_bow.size(); ++g) {
+    for (size_t j = g; j < f0.Size(); j += 9) kf_bow[g][(unsigned)((j * 13) % 97)] += 1.0 + f0.descriptors.data()[32 * j + 1];
+    double sum = 0;
+    for (const auto & kv : kf_bow[g]) sum += std::fabs(kv.second);
+    for (auto & kv : kf_bow[g]) kv.second /= sum;
+    index.Append(100 + g, kf_bow[g]);
+  }
+  index.Erase(104);
+  index.Erase(555);  // absent: no-op
+  index.Append(102, kf_bow[2]);
+  const std::vector<frame::HipKeyFrameIndex::Hit> hits = index.Query(kf_bow[6]);
+
   std::ofstream o(argv[6], std::ios::binary);
   for (const features::Features * f : {&f0, &f1}) {
     put(o, (int32_t)f->Size());
@@ -150,6 +167,8 @@ int main(int argc, char ** argv) {
     put(o, f1.undistorted_keypoints[i][0]); put(o, f1.undistorted_keypoints[i][1]);
     for (int c = 0; c < 3; ++c) put(o, f1.undistorted_and_unprojected_keypoints[i][c]);
   }
+  put(o, (int32_t)hits.size());
+  for (const auto & h : hits) { put(o, h.keyframe_id); put(o, h.shared_words); put(o, h.score); }
   // scalar helpers
   put(o, (uint32_t)fe->PredictScale(1.0, 3.0)); put(o, fe->GetAcceptableSquareError(3));
   features::DescriptorType a, b; std::memcpy(a.d, f0.descriptors.data(), 32); std::memcpy(b.d, f0.descriptors.data() + 32, 32);

@@ -127,6 +127,29 @@ def test_cpp_adapter_end_to_end(oracle, tmp_path):
     pos += n_geom * 41
     wund, wunp, wok = oracle.keypoint_geometry(k1, oracle.camera(258.6, 258.2, 160.2, 120.1, 0, (-0.28, 0.07, 2e-4, 1.8e-5, 0.0)))
     assert np.array_equal(rec["ok"], wok) and np.array_equal(rec["und"], wund) and np.array_equal(rec["unp"], wunp)
+    # HipKeyFrameIndex: the database adapter_main.cpp builds from frame 0's descriptors
+    kf_bow = []
+    for g in range(9):
+        bow = {}
+        for j in range(g, len(d0), 9):
+            w = (j * 13) % 97
+            bow[w] = bow.get(w, 0.0) + (1.0 + float(d0[j, 1]))
+        tot = 0.0
+        for w in sorted(bow):
+            tot += abs(bow[w])
+        kf_bow.append({w: bow[w] / tot for w in sorted(bow)})
+    live = [g for g in range(9) if g != 4]
+    offs = np.cumsum([0] + [len(kf_bow[g]) for g in live]).astype(np.int64)
+    words = np.concatenate([np.fromiter(kf_bow[g].keys(), np.uint32) for g in live])
+    vals = np.concatenate([np.fromiter(kf_bow[g].values(), np.float64) for g in live])
+    q = kf_bow[6]
+    sh, sc = oracle.bow_score(np.fromiter(q.keys(), np.uint32), np.fromiter(q.values(), np.float64), offs, words, vals, 0)
+    n_hits = take("i")
+    got_hits = {}
+    for _ in range(n_hits):
+        kid, shw, score = take("QQd")
+        got_hits[kid] = (shw, score)
+    assert got_hits == {100 + g: (int(sh[n]), float(sc[n])) for n, g in enumerate(live)}
     assert take("I") == oracle.predict_scale(1.0, 3.0, 1.2, 8)
     s3 = 1.0 * 1.2 * 1.2 * 1.2
     assert take("d") == s3 * s3

@@ -143,3 +143,34 @@ def test_features_wire_format_round_trip():
     assert np.array_equal(g.undistorted_and_unprojected_keypoints, f.undistorted_and_unprojected_keypoints)
     empty = Features.Deserialize(Features(64, 48).Serialize())
     assert empty.Size() == 0 and empty.descriptors.shape == (0, 32)
+
+
+def test_keyframe_database_stream_layout():
+    """DBoW2Database::Serialize (frame/database/DBoW2/dbo_w2_database.cpp:39-51): u64 word count, per word u64 entry
+    count then (u64 keyframe id, u64 count) pairs; round trip through the stream constructor (:16-32).  No GPU needed:
+    only the query touches the device."""
+    import io
+    import struct
+    from types import SimpleNamespace
+    from orb_slam3_amd.database import DBoW2Database
+    fe = SimpleNamespace(_lib=None, handle=None)
+    db = DBoW2Database(fe, 6, with_counts=True)
+    db.Append(7, {1: 0.25, 4: 0.75})
+    db.Append(3, {4: 1.0}, {4: 2})
+    db.Append(9, {0: 0.5, 5: 0.5})
+    db.Erase(9)
+    buf = io.BytesIO()
+    db.Serialize(buf)
+    want = struct.pack("<Q", 6) + struct.pack("<Q", 0) + struct.pack("<QQQ", 1, 7, 1) + struct.pack("<Q", 0) * 2 + \
+        struct.pack("<QQQQQ", 2, 3, 2, 7, 1) + struct.pack("<Q", 0)
+    assert buf.getvalue() == want
+    buf.seek(0)
+    back = DBoW2Database.Deserialize(buf, fe, {7: {1: 0.25, 4: 0.75}, 3: {4: 1.0}})
+    assert back.inverted_file == db.inverted_file
+    import pytest
+    with pytest.raises(ValueError):
+        DBoW2Database.Deserialize(io.BytesIO(want[:-4]), fe, {})
+    with pytest.raises(ValueError):
+        db.Append(1, {6: 1.0})
+    with pytest.raises(ValueError):
+        DBoW2Database(fe, 6).Append(1, {2: 1.0}, {2: 3})       # counts need with_counts=True

@@ -562,3 +562,37 @@ def test_keypoint_geometry_vs_literal(oracle):
                 assert tuple(und[i]) == (0.0, 0.0)
         if k and abs(k[0]) > 2:
             assert n_fail > 0          # the failure branches are really exercised
+
+
+@pytest.mark.parametrize("scoring", [0, 1, 2, 4, 5])
+def test_bow_score_vs_literal(oracle, scoring):
+    """oo_bow_score (inverted file + SearchWordSharingKeyFrames + vocabulary score) against the dict-based literal
+    transcription of dbo_w2_database.cpp:53-132 and ScoringObject.cpp."""
+    from db_literal import LiteralDatabase, flatten, l_score, random_database
+    vocab = 500
+    bows, freqs = random_database(40 + scoring, 60, vocab, 80, weighted_counts=True)
+    db = LiteralDatabase(vocab)
+    for k in bows:
+        db.Append(k, bows[k], freqs[k])
+    ids, offs, words, vals, counts = flatten(bows, freqs)
+    for qk in (ids[0], ids[5], ids[17]):
+        q_bow, q_wf = bows[qk], {w: c + 1 for w, c in freqs[qk].items()}
+        qw = np.asarray(sorted(q_bow), np.uint32)
+        qv = np.asarray([q_bow[w] for w in sorted(q_bow)], np.float64)
+        qc = np.asarray([q_wf[w] for w in sorted(q_bow)], np.uint32)
+        shared, score = oracle.bow_score(qw, qv, offs, words, vals, scoring, qc, counts)
+        lit = db.SearchWordSharingKeyFrames(q_wf)
+        for n, k in enumerate(ids):
+            assert int(shared[n]) == lit.get(k, 0)
+            s = l_score(q_bow, bows[k], scoring)
+            assert score[n] == s or (math.isnan(score[n]) and math.isnan(s))
+    # empty query, and counts left out (= 1)
+    shared, score = oracle.bow_score(np.zeros(0, np.uint32), np.zeros(0), offs, words, vals, scoring)
+    assert not shared.any()
+    shared1, _ = oracle.bow_score(qw, qv, offs, words, vals, scoring)
+    lit1 = db_counts_one(bows, q_bow)
+    assert [int(x) for x in shared1] == [lit1[k] for k in ids]
+
+
+def db_counts_one(bows, q_bow):
+    return {k: len(set(bows[k]) & set(q_bow)) for k in bows}
