@@ -101,7 +101,11 @@ int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_
 /* Device-resident form: images, outputs and counts live in HBM.  d_imgs holds n_frames images,
  * frame f at d_imgs + f*frame_stride, rows `stride` bytes apart.  Fully asynchronous: every stage, the
  * quadtree included, is enqueued on the context's stream and the call returns at once; a capacity violation
- * detected on the device is reported (ORBGPU_E_CAPACITY) by the next orbgpu_synchronize / orbgpu_stage_times. */
+ * detected on the device is reported (ORBGPU_E_CAPACITY) by the next orbgpu_synchronize / orbgpu_stage_times.
+ * The images are read where they are (no copy) when stride == width rounded up to a multiple of 16 and d_imgs and
+ * frame_stride are multiples of 16 (the bytes between width and stride may hold anything); any other layout is
+ * copied into the library's frame slabs first.  Either way the images must stay untouched until the work this call
+ * enqueued has completed (orbgpu_synchronize, or an event on orbgpu_stream); they are never written. */
 int orbgpu_extract_batch_device(orbgpu_ctx *ctx, const uint8_t *d_imgs, int64_t frame_stride, int32_t stride,
                                 int32_t n_frames, int32_t feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc,
                                 int32_t capacity, int32_t *d_n_out);

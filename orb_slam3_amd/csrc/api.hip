@@ -393,6 +393,8 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   {
     const char *e = std::getenv("ORBGPU_HOST_QUADTREE");
     ctx->host_quadtree = e && e[0] == '1';
+    const char *z = std::getenv("ORBGPU_NO_ZERO_COPY");
+    ctx->no_zero_copy = z && z[0] == '1';
   }
   auto bail = [&](int rc) {
     g_create_error = ctx->err;
@@ -516,7 +518,17 @@ int orbgpu_extract_batch_device(orbgpu_ctx *ctx, const uint8_t *d_imgs, int64_t 
   if (stride < ctx->params.width) return fail(ctx, ORBGPU_E_INVALID, "stride smaller than width");
   if (capacity < 1) return fail(ctx, ORBGPU_E_CAPACITY, "capacity must be >= 1");
   HIP_TRY(hipSetDevice(ctx->device));
-  launch_import_images(ctx, d_imgs, frame_stride, stride, n_frames);
+  // zero copy: when the caller's rows are laid out like level 0 of the slab (row stride = width rounded up to 16, 16-byte
+  // aligned base and frame stride) every kernel reads level 0 where it is; otherwise it is copied into the slab
+  const LevelGeom &L0 = ctx->geom.lv[0];
+  const bool in_place = stride == L0.pitch && frame_stride >= (int64_t)L0.pitch * L0.h &&
+                        ((reinterpret_cast<uintptr_t>(d_imgs) | (uintptr_t)frame_stride) & 15) == 0 && !ctx->no_zero_copy;
+  if (in_place) {
+    ctx->lvl0 = Level0Src{d_imgs, (long long)frame_stride};
+  } else {
+    ctx->lvl0 = Level0Src{nullptr, 0};
+    launch_import_images(ctx, d_imgs, frame_stride, stride, n_frames);
+  }
   return run_pipeline(ctx, n_frames, feature_count, d_kp, d_desc, capacity, d_n_out);
 }
 
@@ -546,6 +558,7 @@ int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_
     HIP_TRY(hipMemcpyAsync(ctx->d_pyr + (size_t)f * ctx->geom.frame_bytes + L0.off, dst, (size_t)L0.pitch * L0.h,
                            hipMemcpyHostToDevice, ctx->stream));
   }
+  ctx->lvl0 = Level0Src{nullptr, 0};
   const int cap_dev = ctx->out_capacity;
   int rc = run_pipeline(ctx, n_frames, feature_count, ctx->d_out_kp, ctx->d_out_desc, cap_dev, ctx->d_out_n);
   if (rc) return rc;
@@ -593,6 +606,9 @@ int orbgpu_debug_dump(orbgpu_ctx *ctx, int32_t frame, uint8_t *pyramid, uint8_t 
   for (int k = 0; k < 3; k++) {
     if (!dsts[k]) continue;
     HIP_TRY(hipMemcpy(slab.data(), srcs[k] + (size_t)frame * g.frame_bytes, g.frame_bytes, hipMemcpyDeviceToHost));
+    if (k == 0 && ctx->lvl0.base)  // level 0 was read in place
+      HIP_TRY(hipMemcpy(slab.data() + g.lv[0].off, ctx->lvl0.base + (size_t)frame * (size_t)ctx->lvl0.frame_stride,
+                        (size_t)g.lv[0].pitch * g.lv[0].h, hipMemcpyDeviceToHost));
     size_t o = 0;
     for (int l = 0; l < g.levels; l++) {
       const LevelGeom &L = g.lv[l];

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
                                                               const int *__restrict__ kp_count,
                                                               orbgpu_keypoint *__restrict__ out_kp,
                                                               uint8_t *__restrict__ out_desc, int capacity,
-                                                              int *__restrict__ out_n, int n_frames) {
+                                                              int *__restrict__ out_n, int n_frames, Level0Src lvl0) {
   __shared__ unsigned patch[KPG][PATCH_DW];
   __shared__ float s_angle[KPG];
   __shared__ float s_cs[KPG][2];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
 #pragma unroll
   for (int h = 0; h < KPW; h++) {
     const int xo = (cx[h] - ORB_HALF_PATCH) & ~3;
-    const uint8_t *osrc = pyr + (size_t)f * g.frame_bytes + l_off[h] + (size_t)(cy[h] - ORB_HALF_PATCH) * l_pitch[h] + xo;
+    const uint8_t *osrc = level_src(pyr, g, lvl0, f, lv[h], l_off[h]) + (size_t)(cy[h] - ORB_HALF_PATCH) * l_pitch[h] + xo;
     const unsigned ooff = (unsigned)(osub * l_pitch[h] + oc4);
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -268,7 +268,7 @@ void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *
                             int *d_n_out) {
   dim3 grid((c->geom.kps_per_frame + KPG - 1) / KPG * xcd_frames(n_frames));
   hipLaunchKernelGGL(k_orient_describe, grid, dim3(64 * KPB), 0, c->stream, c->d_pyr, c->d_blur, c->geom, c->d_kp_xy,
-                     c->d_kp_count, d_kp, d_desc, capacity, d_n_out, n_frames);
+                     c->d_kp_count, d_kp, d_desc, capacity, d_n_out, n_frames, c->lvl0);
 }
 
 // ------------------------------------------------------------------------------------------------

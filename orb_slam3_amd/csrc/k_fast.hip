@@ -117,7 +117,7 @@ constexpr int FT_H = 32;                 // FAST tile: 128 x 32 pixels, 256 thre
 constexpr int FT_ROWS = FT_H + 6;
 
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ score,
-                                                    unsigned *__restrict__ nzmask, DeviceGeom g, int n_frames) {
+                                                    unsigned *__restrict__ nzmask, DeviceGeom g, int n_frames, Level0Src lvl0) {
   __shared__ unsigned tile[FT_ROWS * TILE_DW];
   __shared__ unsigned out_tile[FT_H * TILE_W / 4];
   __shared__ unsigned short queue[FT_H * TILE_W];
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
   const int tiles_x = (L.w + TILE_W - 1) / TILE_W;
   const int x0 = (t % tiles_x) * TILE_W, y0 = (t / tiles_x) * FT_H;
   const size_t base = (size_t)frame * g.frame_bytes + L.off;
-  const uint8_t *src = pyr + base;
+  const uint8_t *src = level_src(pyr, g, lvl0, frame, l, L.off);
 
   if (threadIdx.x == 0) q_count = 0;
   if (threadIdx.x < FT_H * 4) rowmask[threadIdx.x] = 0;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
 
 void launch_fast_score(const orbgpu_ctx *c, int n_frames) {
   dim3 grid(c->geom.ftiles_per_frame * xcd_frames(n_frames));
-  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_score, c->d_nzmask, c->geom, n_frames);
+  hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_score, c->d_nzmask, c->geom, n_frames, c->lvl0);
 }
 
 void launch_cell_detect(const orbgpu_ctx *c, int n_frames) {

@@ -68,14 +68,14 @@ __device__ __forceinline__ unsigned mad24u(unsigned a, unsigned b, unsigned c) {
 
 __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr, DeviceGeom g, int level,
                                                       const XTab *__restrict__ xtab, const YTab *__restrict__ ytab,
-                                                      int lds_pitch, int n_frames) {
+                                                      int lds_pitch, int n_frames, Level0Src lvl0) {
   extern __shared__ __attribute__((aligned(16))) uint8_t rs_lds[];
   const LevelGeom S = g.lv[level - 1], D = g.lv[level];
   const int tiles_x = (D.w + TILE_W - 1) / TILE_W, tiles_y = (D.h + RS_TILE_H - 1) / RS_TILE_H;
   int t, f;
   if (!xcd_item_frame(tiles_x * tiles_y, n_frames, t, f)) return;
   const int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
-  const uint8_t *src = pyr + (size_t)f * g.frame_bytes + S.off;
+  const uint8_t *src = level_src(pyr, g, lvl0, f, level - 1, S.off);
   uint8_t *dst = pyr + (size_t)f * g.frame_bytes + D.off;
   const XTab *xt = xtab + D.xtab_off;
   const YTab *yt = ytab + D.ytab_off;
@@ -89,14 +89,17 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
   const int ncols16 = (sxb - sxa) / 16 + 1;
   const int nrows = syb - sya + 1;
   {
-    // pitch is a multiple of 16 and slabs are padded, so the 16-byte reads stay inside the slab
+    // pitch is a multiple of 16, so the 16-byte reads stay inside the row; the chunk that would start at the pitch
+    // (column sx0 + 1 of a clamped last column: weight 0, any value will do) is not read -- level 0 may be the caller's
+    // buffer, which ends with its last row
     const float inv = 1.0f / (float)ncols16;
     for (int i = threadIdx.x; i < nrows * ncols16; i += 256) {
       int r = (int)((float)i * inv);  // i < 2^15: at most one off, fixed below
       int c = i - r * ncols16;
       if (c < 0) { r--; c += ncols16; }
       if (c >= ncols16) { r++; c -= ncols16; }
-      const uint4 v = *reinterpret_cast<const uint4 *>(src + (size_t)(sya + r) * S.pitch + sxa + 16 * c);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (sxa + 16 * c < S.pitch) v = *reinterpret_cast<const uint4 *>(src + (size_t)(sya + r) * S.pitch + sxa + 16 * c);
       *reinterpret_cast<uint4 *>(&rs_lds[r * lds_pitch + 16 * c]) = v;
     }
   }
@@ -180,7 +183,7 @@ __device__ __forceinline__ u16x2 hblur_pair(const unsigned (&w)[3]) {
 }
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g,
-                                              int n_frames) {
+                                              int n_frames, Level0Src lvl0) {
   __shared__ unsigned tile[BT_ROWS * TILE_DW];
   __shared__ __attribute__((aligned(16))) unsigned hbuf[BT_PAIRS * TILE_W];  // (h[2m][x], h[2m+1][x]) per dword
   // tile -> (level, tile x, tile y)
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   const int tiles_x = (L.w + TILE_W - 1) / TILE_W;
   const int x0 = (t % tiles_x) * TILE_W, y0 = (t / tiles_x) * BT_H;
   const size_t base = (size_t)frame * g.frame_bytes + L.off;
-  const uint8_t *src = pyr + base;
+  const uint8_t *src = level_src(pyr, g, lvl0, frame, l, L.off);
 
   stage_tile<BT_ROWS, true>(tile, src, L.w, L.h, L.pitch, x0, y0);
   __syncthreads();
@@ -274,10 +277,10 @@ void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level) {
   dim3 grid(((D.w + TILE_W - 1) / TILE_W) * ((D.h + RS_TILE_H - 1) / RS_TILE_H) * xcd_frames(n_frames));
   const size_t lds = (size_t)c->rs_pitch[level] * c->rs_rows[level];
   hipLaunchKernelGGL(k_resize_level, grid, dim3(256), lds, c->stream, c->d_pyr, c->geom, level, c->d_xtab, c->d_ytab,
-                     c->rs_pitch[level], n_frames);
+                     c->rs_pitch[level], n_frames, c->lvl0);
 }
 
 void launch_blur(const orbgpu_ctx *c, int n_frames, hipStream_t stream) {
   dim3 grid(c->geom.ftiles_per_frame * xcd_frames(n_frames));
-  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, stream, c->d_pyr, c->d_blur, c->geom, n_frames);
+  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, stream, c->d_pyr, c->d_blur, c->geom, n_frames, c->lvl0);
 }

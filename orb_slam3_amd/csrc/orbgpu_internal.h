@@ -47,6 +47,17 @@ struct DeviceGeom {
   LevelGeom lv[ORBGPU_MAX_LEVELS];
 };
 
+// Level 0 of the pyramid may stay in the caller's device buffer (orbgpu_extract_batch_device with rows laid out like
+// the slab's): base == nullptr means it was copied into the slab like the other levels.
+struct Level0Src {
+  const uint8_t *base;
+  long long frame_stride;
+};
+__device__ __forceinline__ const uint8_t *level_src(const uint8_t *pyr, const DeviceGeom &g, const Level0Src &z, int frame,
+                                                    int l, unsigned level_off) {
+  return (l == 0 && z.base) ? z.base + (size_t)frame * (size_t)z.frame_stride : pyr + (size_t)frame * g.frame_bytes + level_off;
+}
+
 // level of item `i` given ascending first-item offsets (offs[0] = 0): branch-free, no dependent loads
 __device__ __forceinline__ int level_of(const int (&offs)[ORBGPU_MAX_LEVELS], int i) {
   int l = 0;
@@ -84,6 +95,8 @@ struct orbgpu_ctx {
 
   // device slabs, sized for max_batch frames
   uint8_t *d_pyr = nullptr, *d_score = nullptr, *d_blur = nullptr;
+  Level0Src lvl0{nullptr, 0};     // where the last extract call's level 0 lives (kernel argument of that call)
+  bool no_zero_copy = false;      // ORBGPU_NO_ZERO_COPY=1: always copy level 0 into the slab (cross-check path)
   unsigned *d_nzmask = nullptr;   // [frame][mask_dwords_per_frame]: bit x of row y set iff score(x, y) != 0
   XTab *d_xtab = nullptr;
   YTab *d_ytab = nullptr;

@@ -62,6 +62,57 @@ def test_batch_device_extract_and_link(oracle, W, H, NF, B):
     fe.close()
 
 
+@pytest.mark.parametrize("W,H,row_stride,base_off,frame_pad,in_place", [
+    (324, 244, 324, 0, 0, False),      # width not a multiple of 16, tight rows: level 0 is copied into the slab
+    (324, 244, 336, 0, 64, True),      # rows padded to the slab pitch (pad bytes hold junk), gap between frames: read in place
+    (320, 240, 320, 16, 48, True),     # tight rows are already the slab layout; base 16 bytes into the allocation
+    (320, 240, 320, 4, 0, False),      # base not 16-byte aligned: copied
+    (320, 240, 352, 0, 0, False),      # row stride wider than the pitch: copied
+])
+def test_batch_device_layouts(oracle, W, H, row_stride, base_off, frame_pad, in_place):
+    """orbgpu_extract_batch_device reads level 0 where the caller put it when the layout allows (zero copy) and copies
+    it otherwise; both give the oracle's result, and the debug dump returns the caller's level 0 either way."""
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    B, NF = 3, 300
+    frames = synth.sequence(91, B, H, W)
+    fe = ORBFeatureExtractor(W, H, 1.2, 4, 20, 7, max_batch=B, max_features=NF)
+    cap = fe.geometry(NF).keypoint_capacity
+    dev = torch.device("cuda", 0)
+    frame_stride = row_stride * H + frame_pad
+    host = np.full(base_off + B * frame_stride, 255, np.uint8)       # junk everywhere the images are not
+    for f in range(B):
+        v = host[base_off + f * frame_stride: base_off + f * frame_stride + row_stride * H].reshape(H, row_stride)
+        v[:, :W] = frames[f]
+    d_imgs = torch.from_numpy(host).to(dev)
+    d_kp = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    assert (d_imgs.data_ptr() % 256) == 0
+    rc = lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr() + base_off, frame_stride, row_stride, B, NF,
+                                         d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
+    assert rc == 0, lib.orbgpu_last_error(fe.handle)
+    assert lib.orbgpu_synchronize(fe.handle) == 0
+    assert np.array_equal(d_imgs.cpu().numpy(), host)                # the input is never written
+    n = d_n.cpu().numpy()
+    kp = d_kp.cpu().numpy().view(_lib.KP_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy()
+    p = oracle.params(W, H, levels=4)
+    for f in range(B):
+        k, d, ex = oracle.extract(p, frames[f], NF, dump=True)
+        assert n[f] == len(k) and len(k) > 50
+        for fld in ("x", "y", "level", "size"):
+            assert np.array_equal(kp[f, :n[f]][fld], k[fld]), fld
+        assert np.array_equal(kp[f, :n[f]]["angle"], k["angle"].astype(np.float32))
+        assert np.array_equal(desc[f, :n[f]], d)
+        dump = fe.debug_dump(f)
+        assert np.array_equal(dump["pyramid"][:W * H].reshape(H, W), frames[f])
+        assert np.array_equal(dump["pyramid"], ex["pyramid"]) and np.array_equal(dump["blurred"], ex["blurred"])
+    fe.close()
+
+
 def test_error_behaviour():
     from orb_slam3_amd._lib import OrbGpuError
     from orb_slam3_amd.features import ORBFeatureExtractor, Features
