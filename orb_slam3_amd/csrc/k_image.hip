@@ -150,9 +150,8 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 //   dst = (sum k_j * h[y+j-3] + 32768) >> 16
 // One launch covers all levels of all frames.  Tile 128 x 32, apron 3 rows / 4 columns, both passes in LDS and in
 // packed integer math (the integer VALU, not HBM, is what bounds this kernel):
-//   horizontal: two pixels per op -- v_perm_b32 builds (tap_p, tap_p+1) u16 pairs, v_pk_add/v_pk_mul_lo/v_pk_mad_u16
-//               evaluate the symmetric taps; two rows per lane are interleaved so that LDS holds (row 2m, row 2m+1)
-//               pairs per pixel;
+//   horizontal: per pixel two byte-aligned dwords of the row (v_alignbyte_b32) and two v_dot4_u32_u8 against the
+//               kernel bytes; two rows per lane are interleaved so that LDS holds (row 2m, row 2m+1) pairs per pixel;
 //   vertical:   four v_dot2_u32_u16 per pixel on those row pairs (weights chosen by the parity of the output row).
 constexpr int BT_H = 32;
 constexpr int BT_ROWS = BT_H + 6;        // 38 staged rows = 19 row pairs
@@ -162,24 +161,15 @@ typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
 __device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
-// bytes B and B+1 of the 12-byte window {w0,w1,w2} zero-extended into the two u16 halves
+// horizontal 7-tap of the pixel whose first tap is byte B (1..4) of the 12-byte window {w0,w1,w2}: two byte-aligned
+// dwords (taps 0..3 and 4..7) and two v_dot4_u32_u8 against the kernel (18 34 48 56 | 48 34 18 0); <= 65280
 template <int B>
-__device__ __forceinline__ u16x2 pair_bytes(const unsigned (&w)[3]) {
-  constexpr int lo = B >> 2;
-  constexpr int k0 = B & 3, k1 = k0 + 1;
-  constexpr unsigned sel = (unsigned)k0 | (0x0cu << 8) | ((unsigned)k1 << 16) | (0x0cu << 24);
-  const unsigned hi = w[lo + 1 < 3 ? lo + 1 : 2];
-  return as_u16x2(__builtin_amdgcn_perm(hi, w[lo], sel));
-}
-
-// horizontal 7-tap of the pixel pair whose first tap is byte B of the window
-template <int B>
-__device__ __forceinline__ u16x2 hblur_pair(const unsigned (&w)[3]) {
-  const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
-  const u16x2 s0 = pair_bytes<B>(w) + pair_bytes<B + 6>(w);
-  const u16x2 s1 = pair_bytes<B + 1>(w) + pair_bytes<B + 5>(w);
-  const u16x2 s2 = pair_bytes<B + 2>(w) + pair_bytes<B + 4>(w);
-  return s0 * k18 + s1 * k34 + s2 * k48 + pair_bytes<B + 3>(w) * k56;
+__device__ __forceinline__ unsigned hblur_px(const unsigned (&w)[3]) {
+  constexpr unsigned K0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K1 = 48u | (34u << 8) | (18u << 16);
+  // v_alignbyte_b32 shifts by 0..3 bytes: B == 4 is the aligned case
+  const unsigned t0 = B == 4 ? w[1] : __builtin_amdgcn_alignbyte(w[1], w[0], B & 3);   // bytes B .. B+3
+  const unsigned t1 = B == 4 ? w[2] : __builtin_amdgcn_alignbyte(w[2], w[1], B & 3);   // bytes B+4 .. B+7
+  return __builtin_amdgcn_udot4(t1, K1, __builtin_amdgcn_udot4(t0, K0, 0u, false), false);
 }
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g,
@@ -211,13 +201,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
       w1[q] = tile[(2 * rp + 1) * TILE_DW + c + q];
     }
     // window bytes 0..11 = columns 4c-4 .. 4c+7 (relative to x0); pixel p has its centre at byte 4+p, first tap 1+p
-    const unsigned a01 = as_u32(hblur_pair<1>(w0)), a23 = as_u32(hblur_pair<3>(w0));
-    const unsigned b01 = as_u32(hblur_pair<1>(w1)), b23 = as_u32(hblur_pair<3>(w1));
-    uint4 o;
-    o.x = __builtin_amdgcn_perm(b01, a01, 0x05040100u);  // pixel 0: (row 2rp, row 2rp+1)
-    o.y = __builtin_amdgcn_perm(b01, a01, 0x07060302u);  // pixel 1
-    o.z = __builtin_amdgcn_perm(b23, a23, 0x05040100u);
-    o.w = __builtin_amdgcn_perm(b23, a23, 0x07060302u);
+    uint4 o;  // per pixel (row 2rp, row 2rp+1) as u16 halves
+    o.x = hblur_px<1>(w0) | (hblur_px<1>(w1) << 16);
+    o.y = hblur_px<2>(w0) | (hblur_px<2>(w1) << 16);
+    o.z = hblur_px<3>(w0) | (hblur_px<3>(w1) << 16);
+    o.w = hblur_px<4>(w0) | (hblur_px<4>(w1) << 16);
     *reinterpret_cast<uint4 *>(&hbuf[rp * TILE_W + 4 * c]) = o;
   }
   __syncthreads();
