@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--no-allpairs", action="store_true", help="skip the keyframe all-pairs section (SURVEY 8e)")
     ap.add_argument("--keyframe-every", type=int, default=4)
     ap.add_argument("--no-database", action="store_true", help="skip the keyframe-database query section (SURVEY 8f.4)")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive host-pointer measurement")
     args = ap.parse_args()
 
     import torch
@@ -227,6 +228,32 @@ def main():
                     "frac_of_nominal_peak": round(n * n / bf / nominal, 4),
                     "n_matched": int((di >= 0).sum().item())}
 
+    host_path = {}
+    if not args.no_host_path and world == 1:
+        # the boundary the reference's caller uses: host images in, host keypoints / descriptors out (orbgpu_extract_batch),
+        # PCIe transfers and host staging included -- informational, never part of `value`
+        import ctypes as C
+        ptrs = (C.c_void_p * B)(*[frames[i].ctypes.data for i in range(B)])
+        h_kp = np.zeros((B, cap), _lib.KP_DTYPE)
+        h_desc = np.zeros((B, cap, 32), np.uint8)
+        h_n = np.zeros(B, np.int32)
+        times = []
+        for it in range(4):
+            t1 = time.perf_counter()
+            check(lib.orbgpu_extract_batch(fe.handle, ptrs, B, W, NF, _lib.ptr(h_kp), _lib.ptr(h_desc), cap, _lib.ptr(h_n)))
+            times.append(time.perf_counter() - t1)
+        hp = min(times[1:])
+        # one frame per call, as IFeatureExtractor::Extract is called by the reference (feature_handler_factory.cpp:50)
+        one = []
+        for it in range(12):
+            t1 = time.perf_counter()
+            check(lib.orbgpu_extract_batch(fe.handle, ptrs, 1, W, NF, _lib.ptr(h_kp), _lib.ptr(h_desc), cap, _lib.ptr(h_n)))
+            one.append(time.perf_counter() - t1)
+        host_path = {"frames_per_s": round(B / hp, 1), "ms_per_batch": round(hp * 1e3, 3),
+                     "single_frame_call_ms": round(float(np.median(one[2:])) * 1e3, 4),
+                     "bytes_in_per_frame": W * H, "bytes_out_per_frame_mean": int(round(float(h_n.mean()) * 64)),
+                     "includes": "host row copies into pinned memory (8 threads for a batch), H2D, extraction, D2H of keypoints and descriptors; synchronous call"}
+
     database = {}
     if not args.no_database:
         # place recognition (DBoW2Database::DetectNBestCandidates' query half): one BowVector against 20,000 resident
@@ -303,7 +330,8 @@ def main():
                       "link_matches_mean": round(float(n_matches.mean()), 1) if n_pairs else 0.0,
                       "parallelism": f"frame-sharded x{world}"},
            "roofline": roofline, "pipeline": pipeline, "matching": matching, "keyframe_allpairs": allpairs,
-           "keyframe_database": database, "cpu_baseline": cpu}
+           "keyframe_database": database, "host_pointer_path": host_path,
+           "cpu_baseline": cpu}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -466,7 +466,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
                    ctx->d_error_flag};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
-  void *hptrs[] = {ctx->h_cells, ctx->h_cands, ctx->h_kp_xy, ctx->h_kp_count, ctx->h_imgs, ctx->h_error_flag};
+  void *hptrs[] = {ctx->h_cells, ctx->h_cands, ctx->h_kp_xy, ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};
   for (void *p : hptrs)
     if (p) (void)hipHostFree(p);
   for (auto &set : ctx->ev)
@@ -548,15 +548,35 @@ int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_
   HIP_TRY(hipSetDevice(ctx->device));
   const LevelGeom &L0 = ctx->geom.lv[0];
   if (!ctx->h_imgs) HIP_TRY(hmalloc(&ctx->h_imgs, (size_t)ctx->params.max_batch * L0.pitch * L0.h));
-  // host -> pinned (pitch layout) -> level 0 of each frame slab
-  for (int f = 0; f < n_frames; f++) {
+  // host -> pinned (pitch layout) -> level 0 of each frame slab.  The row copies of a batch are spread over a few host
+  // threads (a frame's upload is enqueued by the thread that staged it; the kernels are enqueued after the join)
+  auto stage_frame = [&](int f) -> hipError_t {
     uint8_t *dst = ctx->h_imgs + (size_t)f * L0.pitch * L0.h;
-    for (int y = 0; y < h; y++) {
-      std::memcpy(dst + (size_t)y * L0.pitch, imgs[f] + (size_t)y * stride, (size_t)w);
-      std::memset(dst + (size_t)y * L0.pitch + w, 0, (size_t)(L0.pitch - w));
+    if (stride == L0.pitch) {
+      std::memcpy(dst, imgs[f], (size_t)L0.pitch * (h - 1) + w);
+    } else {
+      for (int y = 0; y < h; y++) {
+        std::memcpy(dst + (size_t)y * L0.pitch, imgs[f] + (size_t)y * stride, (size_t)w);
+        std::memset(dst + (size_t)y * L0.pitch + w, 0, (size_t)(L0.pitch - w));
+      }
     }
-    HIP_TRY(hipMemcpyAsync(ctx->d_pyr + (size_t)f * ctx->geom.frame_bytes + L0.off, dst, (size_t)L0.pitch * L0.h,
-                           hipMemcpyHostToDevice, ctx->stream));
+    return hipMemcpyAsync(ctx->d_pyr + (size_t)f * ctx->geom.frame_bytes + L0.off, dst, (size_t)L0.pitch * L0.h,
+                          hipMemcpyHostToDevice, ctx->stream);
+  };
+  const int n_thr = n_frames >= 8 ? std::min(std::min(8, n_frames / 4), (int)std::max(1u, std::thread::hardware_concurrency())) : 1;
+  if (n_thr <= 1) {
+    for (int f = 0; f < n_frames; f++) HIP_TRY(stage_frame(f));
+  } else {
+    std::vector<hipError_t> err((size_t)n_thr, hipSuccess);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_thr; t++)
+      pool.emplace_back([&, t] {
+        hipError_t e = hipSetDevice(ctx->device);
+        for (int f = t; f < n_frames && e == hipSuccess; f += n_thr) e = stage_frame(f);
+        err[(size_t)t] = e;
+      });
+    for (auto &th : pool) th.join();
+    for (hipError_t e : err) HIP_TRY(e);
   }
   ctx->lvl0 = Level0Src{nullptr, 0};
   const int cap_dev = ctx->out_capacity;
@@ -570,14 +590,38 @@ int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_
     if (tot > cap_dev) return fail(ctx, ORBGPU_E_CAPACITY, "internal keypoint capacity too small: need " + std::to_string(tot));
     if (tot > capacity) return fail(ctx, ORBGPU_E_CAPACITY, "caller capacity too small: need " + std::to_string(tot));
     n_out[f] = tot;
-    if (tot) {
+  }
+  if (n_thr <= 1) {
+    for (int f = 0; f < n_frames; f++) {
+      const int tot = ctx->h_kp_count[f];
+      if (!tot) continue;
       HIP_TRY(hipMemcpyAsync(kp + (size_t)f * capacity, ctx->d_out_kp + (size_t)f * cap_dev, sizeof(orbgpu_keypoint) * tot,
                              hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipMemcpyAsync(desc + (size_t)f * capacity * 32, ctx->d_out_desc + (size_t)f * cap_dev * 32, (size_t)tot * 32,
                              hipMemcpyDeviceToHost, ctx->stream));
     }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ORBGPU_OK;
   }
+  // batch: two large downloads into pinned memory, then the per-frame pieces are copied out by the same few threads
+  const size_t kp_bytes = (size_t)n_frames * cap_dev * sizeof(orbgpu_keypoint), desc_bytes = (size_t)n_frames * cap_dev * 32;
+  if (!ctx->h_out) HIP_TRY(hmalloc(&ctx->h_out, (size_t)ctx->params.max_batch * cap_dev * (sizeof(orbgpu_keypoint) + 32)));
+  uint8_t *h_desc = ctx->h_out + (size_t)ctx->params.max_batch * cap_dev * sizeof(orbgpu_keypoint);
+  HIP_TRY(hipMemcpyAsync(ctx->h_out, ctx->d_out_kp, kp_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(h_desc, ctx->d_out_desc, desc_bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_thr; t++)
+      pool.emplace_back([&, t] {
+        for (int f = t; f < n_frames; f += n_thr) {
+          const size_t tot = (size_t)ctx->h_kp_count[f];
+          std::memcpy(kp + (size_t)f * capacity, ctx->h_out + (size_t)f * cap_dev * sizeof(orbgpu_keypoint), tot * sizeof(orbgpu_keypoint));
+          std::memcpy(desc + (size_t)f * capacity * 32, h_desc + (size_t)f * cap_dev * 32, tot * 32);
+        }
+      });
+    for (auto &th : pool) th.join();
+  }
   return ORBGPU_OK;
 }
 

@@ -124,6 +124,7 @@ struct orbgpu_ctx {
   short2 *h_kp_xy = nullptr;
   int *h_kp_count = nullptr;
   uint8_t *h_imgs = nullptr;  // pinned upload buffer for host-pointer extraction
+  uint8_t *h_out = nullptr;   // pinned download buffer of the batched host-pointer extraction: keypoints, then descriptors
 
   // matching scratch (grown on demand)
   void *d_match_scratch = nullptr;

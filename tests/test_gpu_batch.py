@@ -113,6 +113,49 @@ def test_batch_device_layouts(oracle, W, H, row_stride, base_off, frame_pad, in_
     fe.close()
 
 
+@pytest.mark.parametrize("W,H,pad", [(320, 240, 0), (324, 244, 0), (320, 240, 32)])
+def test_host_batch_threaded_path(oracle, W, H, pad):
+    """orbgpu_extract_batch with enough frames for its multi-threaded staging / bulk download path (>= 8): tight
+    rows that equal the slab pitch, a width that needs re-pitching, and padded rows; one frame is featureless."""
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    B, NF = 13, 250
+    frames = synth.sequence(93, B, H, W)
+    frames[5][:] = 77                                   # no corners: an empty slot in the middle of the batch
+    imgs = []
+    for f in range(B):
+        buf = np.full((H, W + pad), 200, np.uint8)
+        buf[:, :W] = frames[f]
+        imgs.append(buf[:, :W])                         # row stride W + pad
+    fe = ORBFeatureExtractor(W, H, 1.2, 4, 20, 7, max_batch=B, max_features=NF)
+    if pad == 0:
+        got = fe.ExtractBatch(imgs, NF)
+    else:                                               # ExtractBatch makes rows contiguous; pass the padded rows as they are
+        import ctypes as C
+        from orb_slam3_amd import _lib
+        from orb_slam3_amd.features import Features
+        cap = fe.geometry(NF).keypoint_capacity
+        kp = np.zeros((B, cap), _lib.KP_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        ptrs = (C.c_void_p * B)(*[im.ctypes.data for im in imgs])
+        rc = fe._lib.orbgpu_extract_batch(fe.handle, ptrs, B, W + pad, NF, _lib.ptr(kp), _lib.ptr(desc), cap, _lib.ptr(n))
+        assert rc == 0, fe._lib.orbgpu_last_error(fe.handle)
+        got = []
+        for f in range(B):
+            ft = Features(W, H)
+            ft.keypoints, ft.descriptors = kp[f, :n[f]], desc[f, :n[f]]
+            got.append(ft)
+    p = oracle.params(W, H, levels=4)
+    for f in range(B):
+        k, d = oracle.extract(p, frames[f], NF)
+        assert got[f].Size() == len(k) and (len(k) > 50) == (f != 5)
+        for fld in ("x", "y", "level", "size"):
+            assert np.array_equal(got[f].keypoints[fld], k[fld]), fld
+        assert np.array_equal(got[f].keypoints["angle"], k["angle"].astype(np.float32))
+        assert np.array_equal(got[f].descriptors, d)
+    fe.close()
+
+
 def test_error_behaviour():
     from orb_slam3_amd._lib import OrbGpuError
     from orb_slam3_amd.features import ORBFeatureExtractor, Features
