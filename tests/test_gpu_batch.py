@@ -170,3 +170,43 @@ def test_error_behaviour():
     fe.close()
     with pytest.raises(OrbGpuError):
         ORBFeatureExtractor(64, 64, 1.2, 8, 20, 7)                          # top levels smaller than a FAST cell
+
+
+def test_concurrent_callers(oracle):
+    """The reference calls the extractor from its main thread and the matchers from three threads at once
+    (SURVEY 8b): a context serialises its own calls, separate contexts run side by side.  Four threads, two of them
+    sharing one context, each extracting and matching repeatedly; every result must equal the single-threaded one."""
+    import threading
+    from orb_slam3_amd.features import Features, ORBFeatureExtractor, SNNMatcher
+    W, H, NF = 320, 240, 300
+    frames = synth.sequence(95, 4, H, W)
+    p = oracle.params(W, H, levels=4)
+    want = [oracle.extract(p, fr, NF) for fr in frames]
+    shared = ORBFeatureExtractor(W, H, 1.2, 4, 20, 7, max_features=NF)
+    own = [ORBFeatureExtractor(W, H, 1.2, 4, 20, 7, max_features=NF) for _ in range(2)]
+    errors = []
+
+    def worker(fe, tid):
+        try:
+            for it in range(6):
+                i = (tid + it) % 4
+                ft = Features(W, H)
+                assert fe.Extract(frames[i], ft, NF) == 0
+                k, d = want[i]
+                assert ft.Size() == len(k) and np.array_equal(ft.descriptors, d)
+                assert np.array_equal(ft.keypoints["x"], k["x"]) and np.array_equal(ft.keypoints["y"], k["y"])
+                j = (i + 1) % 4
+                m, _ = SNNMatcher(0.9, 50, fe).MatchRaw(d, want[j][1])
+                om, _ = oracle.snn_match(d, want[j][1], 50, 0.9)
+                assert np.array_equal(m, om)
+        except Exception as e:   # noqa: BLE001 - reported by the main thread
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(fe, t)) for t, fe in enumerate([shared, shared, own[0], own[1]])]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for fe in [shared] + own:
+        fe.close()
+    assert not errors, errors
