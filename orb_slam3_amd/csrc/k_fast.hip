@@ -321,13 +321,15 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
     if (4 * dd + b >= cxa && 4 * dd + b < cxa + rw) bmask |= 0xffu << (8 * b);
 
   // ---- stage the rectangle (4 rows per step, all loads in flight) ------------------------------------------
-  unsigned w[16];  // rh <= 64 = 16 steps of 4 rows
+  // no per-lane predication: rows / dwords beyond the rectangle load a clamped (in-bounds) address and are masked to 0
+  unsigned w[16];  // rh <= cell_rows <= 64 = 16 steps of 4 rows
+  const uint8_t *lsrc = src + (size_t)y0 * L.pitch + xa + 4 * min(dd, ndwr - 1);
 #pragma unroll
   for (int u = 0; u < 16; u++) {
     const int r = 4 * u + rsub;
     w[u] = 0;
-    if (4 * u < rh)  // uniform
-      if (r < rh && dd < ndwr) w[u] = *reinterpret_cast<const unsigned *>(src + (size_t)(y0 + r) * L.pitch + xa + 4 * dd) & bmask;
+    if (4 * u < cell_rows)  // kernel-uniform
+      w[u] = *reinterpret_cast<const unsigned *>(lsrc + (size_t)min(r, rh - 1) * L.pitch) & (r < rh ? bmask : 0u);
   }
   // ---- queue of the non-zero pixels in raster order, from the bit plane k_fast_score wrote: lane = row ---------
   unsigned long long rowbits = 0;
@@ -352,8 +354,7 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
 #pragma unroll
   for (int u = 0; u < 16; u++) {
     const int r = 4 * u + rsub;
-    if (4 * u < rh)
-      if (r < rh) s32[(r + 2) * CELL_DW + dd] = w[u];
+    if (4 * u < cell_rows) s32[(r + 2) * CELL_DW + dd] = w[u];  // rows rh .. cell_rows-1 receive zeros
   }
   if (lane < 2 * CELL_DW) s32[lane] = 0;                             // the two zero rows above the rectangle
   else if (lane < 3 * CELL_DW) s32[(rh + 2) * CELL_DW + (lane - 2 * CELL_DW)] = 0;  // and the one below
