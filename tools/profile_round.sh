@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 bench.py > $OUT/bench_under_trace.json 2> $OUT/trace.log
 echo trace done
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bruteforce --no-database --no-host-path"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bruteforce --no-database"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- $BENCH > $OUT/pmc_fetch.log 2>&1
 echo fetch done
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write --output-format csv -- $BENCH > $OUT/pmc_write.log 2>&1
