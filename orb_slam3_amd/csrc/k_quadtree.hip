@@ -21,8 +21,8 @@
 
 namespace {
 
-constexpr int QT_THREADS = 256;
-constexpr int QT_WAVES = QT_THREADS / 64;
+// workgroup size NT is a template parameter: 256 threads for VGA-class levels (a few thousand keys, short dependent
+// rounds), 1024 for large images, where a round moves tens of thousands of keys (launch_quadtree chooses)
 constexpr int QT_LDS_KEYS = 2048;   // keys per ping-pong buffer kept in LDS; larger levels use global scratch
 constexpr int QT_SMALL = 64;        // nodes up to this many keys are partitioned by a group of 16 lanes (4 nodes per wave)
 
@@ -53,11 +53,12 @@ struct QShared {
   unsigned char *flag;
 };
 
-// exclusive prefix sum over a[0..n) in place (LDS), all QT_THREADS threads; returns the total
+// exclusive prefix sum over a[0..n) in place (LDS), all NT threads; returns the total
+template <int NT>
 __device__ u64 block_excl_scan(u64 *a, int n, u64 *wsum) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u64 carry = 0;
-  for (int base = 0; base < n; base += QT_THREADS) {
+  for (int base = 0; base < n; base += NT) {
     const int i = base + threadIdx.x;
     const u64 v = i < n ? a[i] : 0;
     u64 incl = v;
@@ -70,7 +71,7 @@ __device__ u64 block_excl_scan(u64 *a, int n, u64 *wsum) {
     __syncthreads();
     u64 woff = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < QT_WAVES; w++) {
+    for (int w = 0; w < (NT / 64); w++) {
       const u64 s = wsum[w];
       if (w < wave) woff += s;
       tot += s;
@@ -137,12 +138,12 @@ __device__ __forceinline__ void node_mid(const QNode &P, int &mx, int &my) {
 // contiguous quarter of the keys, counts its classes, and scatters behind the waves before it.  Keys are fetched four
 // wave-steps at a time so that (global) loads overlap.  classify(key) returns 0..3.  All threads call it together.
 constexpr int QT_BIG = 512;
-template <class KT, class F>
+template <int NT, class KT, class F>
 __device__ __forceinline__ uint4 partition_block(const KT *__restrict__ src, KT *__restrict__ dst, int beg, int cnt, F classify) {
-  __shared__ int wc[QT_WAVES][4];
+  __shared__ int wc[(NT / 64)][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const u64 below = (1ull << lane) - 1ull;
-  const int chunk = (((cnt + QT_WAVES - 1) / QT_WAVES) + 63) & ~63;
+  const int chunk = (((cnt + (NT / 64) - 1) / (NT / 64)) + 63) & ~63;
   const int b0 = min(wave * chunk, cnt), b1 = min(b0 + chunk, cnt);
   int c[4] = {0, 0, 0, 0};
   for (int k0 = b0; k0 < b1; k0 += 256) {
@@ -166,7 +167,7 @@ __device__ __forceinline__ uint4 partition_block(const KT *__restrict__ src, KT 
   for (int qq = 0; qq < 4; qq++) {
     tot[qq] = 0;
     o[qq] = 0;
-    for (int w = 0; w < QT_WAVES; w++) {
+    for (int w = 0; w < (NT / 64); w++) {
       if (w < wave) o[qq] += wc[w][qq];
       tot[qq] += wc[w][qq];
     }
@@ -199,7 +200,7 @@ __device__ __forceinline__ uint4 partition_block(const KT *__restrict__ src, KT 
 
 
 // divide the keys of the listed nodes (list positions idx[k], or k itself when idx == nullptr)
-template <class KT>
+template <int NT, class KT>
 // max_cnt: an upper bound of the listed nodes' key counts (lets whole size classes be skipped without scanning the list)
 __device__ __forceinline__ void partition_nodes(const QShared &S, KT *keys0, KT *keys1, const unsigned short *idx, int count,
                                                 int max_cnt) {
@@ -213,12 +214,12 @@ __device__ __forceinline__ void partition_nodes(const QShared &S, KT *keys0, KT 
     const int b = (int)(P.cnt >> 31);
     int mx, my;
     node_mid(P, mx, my);
-    const uint4 c = partition_block(b ? keys1 : keys0, b ? keys0 : keys1, (int)P.beg, cnt,
+    const uint4 c = partition_block<NT>(b ? keys1 : keys0, b ? keys0 : keys1, (int)P.beg, cnt,
                                     [mx, my](unsigned key) { return quadrant(key, mx, my); });
     if (threadIdx.x == 0) S.qc[i] = c;
   }
   // large nodes: one wave each
-  for (int k = wave; k < count && max_cnt > QT_SMALL; k += QT_WAVES) {
+  for (int k = wave; k < count && max_cnt > QT_SMALL; k += (NT / 64)) {
     const int i = idx ? idx[k] : k;
     const QNode P = S.cur[i];
     const int cnt = (int)(P.cnt & 0x7fffffffu);
@@ -235,7 +236,7 @@ __device__ __forceinline__ void partition_nodes(const QShared &S, KT *keys0, KT 
   {
     const int lane = threadIdx.x & 63, grp = lane >> 4, gl = lane & 15;
     const unsigned gbelow = (1u << gl) - 1u;
-    for (int base = wave * 4; base < count; base += QT_WAVES * 4) {  // uniform per wave
+    for (int base = wave * 4; base < count; base += (NT / 64) * 4) {  // uniform per wave
       const int k = base + grp;
       int i = 0, cnt = 0, beg = 0, mx = 0, my = 0;
       const KT *src = keys0;
@@ -338,7 +339,7 @@ struct QtArgs {
 // that the partition loops use LDS instructions: with a run-time choice the pointers are generic and every key access
 // becomes a flat load / store (measured: 0.5-1 microsecond per dependent step).
 #define STAMP(i) do { if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[i] = wall_clock64(); } while (0)
-template <bool IN_LDS>
+template <int NT, bool IN_LDS>
 __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, const LevelGeom &L, const int l, const int f,
                                        const int n, QShared S, unsigned *lds_keys, u64 *wsum, int *s_misc,
                                        const CellEntry *cells, const int *cpre) {
@@ -357,7 +358,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     // pool (cell index x slot size, k_cell_detect), so the candidate loads do not wait for the cell table
     const int sub = tid & 15;
     const int slot = ((L.wcell + 1) >> 1) * ((L.hcell + 1) >> 1);
-    constexpr int CS = QT_THREADS / 16;
+    constexpr int CS = NT / 16;
     for (int c0 = tid >> 4; c0 < n_cells; c0 += 4 * CS) {
       int cnt[4], o[4];
       unsigned v[4];
@@ -395,7 +396,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
   } else {
     if (nIni <= 4) {
       // the whole workgroup buckets the keys into buffer B (stable), then the roots live in B
-      const uint4 bc = partition_block(keys0, keys1, 0, n, [hX, nIni](unsigned key) {
+      const uint4 bc = partition_block<NT>(keys0, keys1, 0, n, [hX, nIni](unsigned key) {
         return min(max((int)__fdiv_rn((float)key_x(key), hX), 0), nIni - 1);
       });
       if (tid == 0) {
@@ -462,24 +463,24 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     const int rr_ = a.prof ? min((int)a.prof[15] - 1, 3) : 0;
     if (a.prof) __syncthreads();
     STAMP(16 + 4 * rr_);
-    partition_nodes<KT>(S, keys0, keys1, nullptr, Sz, max_cnt);
+    partition_nodes<NT, KT>(S, keys0, keys1, nullptr, Sz, max_cnt);
     __syncthreads();
     STAMP(17 + 4 * rr_);
-    for (int i = tid; i < Sz; i += QT_THREADS) {
+    for (int i = tid; i < Sz; i += NT) {
       const unsigned cnt = S.cur[i].cnt & 0x7fffffffu;
       const uint4 c = S.qc[i];
       S.pre[i] = cnt > 1 ? pack3(n_children(c), 0, n_multi(c)) : pack3(0, 1, 0);
     }
     if (tid == 0) s_misc[2] = 1;  // max child count of this round (the scan's barriers order it before the emit)
     __syncthreads();
-    const u64 tot = block_excl_scan(S.pre, Sz, wsum);
+    const u64 tot = block_excl_scan<NT>(S.pre, Sz, wsum);
     const int ct = (int)f0(tot), kt = (int)f1(tot), mt = (int)f2(tot);
     if (ct + kt > cap) {  // cannot happen: the list never exceeds max(nF + 3, 4 nIni)
       if (tid == 0) atomicExch(a.error_flag, 1);
       Sz = 0;
       break;
     }
-    for (int i = tid; i < Sz; i += QT_THREADS) {
+    for (int i = tid; i < Sz; i += NT) {
       const QNode P = S.cur[i];
       const u64 pr = S.pre[i];
       if ((P.cnt & 0x7fffffffu) > 1) emit_children(S, P, S.qc[i], (int)f0(pr), ct, (int)f2(pr), &s_misc[2]);
@@ -505,16 +506,16 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     if (m == 0) break;  // nothing left to divide: size == prevSize (:477)
     if (a.prof) __syncthreads();
     STAMP(32);
-    partition_nodes<KT>(S, keys0, keys1, S.vs, m, max_cnt);  // nodes only shrink: the bound of phase 1 still holds
+    partition_nodes<NT, KT>(S, keys0, keys1, S.vs, m, max_cnt);  // nodes only shrink: the bound of phase 1 still holds
     if (a.prof) __syncthreads();
     STAMP(33);
     // processing order: descending (size, creation order); rank by counting
     // (sizes first gathered into a flat LDS array -- pre2 is free here -- so the O(m^2) count reads one broadcast
     // word per step instead of chasing vs -> node -> cnt)
     unsigned *sz = reinterpret_cast<unsigned *>(S.pre2);
-    for (int k = tid; k < m; k += QT_THREADS) sz[k] = S.cur[S.vs[k]].cnt & 0x7fffffffu;
+    for (int k = tid; k < m; k += NT) sz[k] = S.cur[S.vs[k]].cnt & 0x7fffffffu;
     __syncthreads();
-    for (int k = tid; k < m; k += QT_THREADS) {
+    for (int k = tid; k < m; k += NT) {
       const unsigned ck = sz[k];
       int rank = 0;
 #pragma unroll 8
@@ -524,19 +525,19 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
       }
       S.ord[rank] = (unsigned short)k;
     }
-    for (int i = tid; i < Sz; i += QT_THREADS) S.flag[i] = 0;
+    for (int i = tid; i < Sz; i += NT) S.flag[i] = 0;
     __syncthreads();
     // inclusive growth of the list along the processing order -> cut (:474)
-    for (int r = tid; r < m; r += QT_THREADS) {
+    for (int r = tid; r < m; r += NT) {
       const uint4 c = S.qc[S.vs[S.ord[r]]];
       S.pre[r] = pack3(n_children(c), 0, n_multi(c));
     }
     __syncthreads();
-    block_excl_scan(S.pre, m, wsum);
+    block_excl_scan<NT>(S.pre, m, wsum);
     // first r with prevSize + (children through r) - (r + 1) >= nF
     if (tid == 0) s_misc[1] = m;
     __syncthreads();
-    for (int r = tid; r < m; r += QT_THREADS) {
+    for (int r = tid; r < m; r += NT) {
       const uint4 c = S.qc[S.vs[S.ord[r]]];
       const int grown = prevSize + (int)f0(S.pre[r]) + (int)n_children(c) - (r + 1);
       if (grown >= nF) atomicMin(&s_misc[1], r + 1);
@@ -551,22 +552,22 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
       ct = (int)f0(S.pre[rl]) + (int)n_children(c);
       mt = (int)f2(S.pre[rl]) + (int)n_multi(c);
     }
-    for (int r = tid; r < nproc; r += QT_THREADS) S.flag[S.vs[S.ord[r]]] = 1;
+    for (int r = tid; r < nproc; r += NT) S.flag[S.vs[S.ord[r]]] = 1;
     __syncthreads();
     // survivors of the old list keep their order behind the new children
-    for (int i = tid; i < Sz; i += QT_THREADS) S.pre2[i] = S.flag[i] ? 0ull : 1ull;
+    for (int i = tid; i < Sz; i += NT) S.pre2[i] = S.flag[i] ? 0ull : 1ull;
     __syncthreads();
-    const int kt = (int)block_excl_scan(S.pre2, Sz, wsum);
+    const int kt = (int)block_excl_scan<NT>(S.pre2, Sz, wsum);
     if (ct + kt > cap) {
       if (tid == 0) atomicExch(a.error_flag, 1);
       Sz = 0;
       break;
     }
-    for (int r = tid; r < nproc; r += QT_THREADS) {
+    for (int r = tid; r < nproc; r += NT) {
       const int i = S.vs[S.ord[r]];
       emit_children(S, S.cur[i], S.qc[i], (int)f0(S.pre[r]), ct, (int)f2(S.pre[r]), nullptr);
     }
-    for (int i = tid; i < Sz; i += QT_THREADS)
+    for (int i = tid; i < Sz; i += NT)
       if (!S.flag[i]) S.nxt[ct + (int)S.pre2[i]] = S.cur[i];
     __syncthreads();
     { QNode *t = S.cur; S.cur = S.nxt; S.nxt = t; }
@@ -583,7 +584,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     if (tid == 0) atomicExch(a.error_flag, 3);
     Sz = 0;
   }
-  for (int i = tid; i < Sz; i += QT_THREADS) {
+  for (int i = tid; i < Sz; i += NT) {
     const QNode P = S.cur[i];
     const KT *keys = (P.cnt >> 31) ? keys1 : keys0;
     const int cnt = (int)(P.cnt & 0x7fffffffu);
@@ -600,9 +601,10 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
   if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[13] = Sz;
 }
 
-__global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a) {
+template <int NT>
+__global__ __launch_bounds__(NT) void k_quadtree(DeviceGeom g, QtArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ u64 wsum[QT_WAVES];
+  __shared__ u64 wsum[(NT / 64)];
   __shared__ int s_misc[8];
   STAMP(0);
   const int l = blockIdx.x, f = blockIdx.y;
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a)
   int n = 0;
   {
     int carry = 0;
-    for (int base = 0; base < n_cells; base += QT_THREADS) {
+    for (int base = 0; base < n_cells; base += NT) {
       const int i = base + tid;
       const int v = i < n_cells ? cells[i].count : 0;
       int incl = v;
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a)
       __syncthreads();
       int woff = 0, tot = 0;
 #pragma unroll
-      for (int w = 0; w < QT_WAVES; w++) {
+      for (int w = 0; w < (NT / 64); w++) {
         const int s = (int)wsum[w];
         if (w < wave) woff += s;
         tot += s;
@@ -658,8 +660,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(DeviceGeom g, QtArgs a)
     n = carry;
   }
   STAMP(1);
-  if (n <= QT_LDS_KEYS) qt_run<true>(g, a, L, l, f, n, S, lds_keys, wsum, s_misc, cells, cpre);
-  else qt_run<false>(g, a, L, l, f, n, S, lds_keys, wsum, s_misc, cells, cpre);
+  if (n <= QT_LDS_KEYS) qt_run<NT, true>(g, a, L, l, f, n, S, lds_keys, wsum, s_misc, cells, cpre);
+  else qt_run<NT, false>(g, a, L, l, f, n, S, lds_keys, wsum, s_misc, cells, cpre);
 }
 
 }  // namespace
@@ -689,16 +691,24 @@ int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
   a.node_cap = cap;
   const size_t lds = quadtree_lds_bytes(cap);
   if (lds > 160 * 1024) return -1;
-  static size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return -1;
-    configured = lds;
+  // a level of a VGA-class image holds a few thousand candidates: 256 threads keep its short dependent rounds cheap
+  // (measured with 512: 0.15 -> 0.34 ms per 256-frame batch); from about a megapixel on a round moves tens of thousands
+  // of keys and 1024 threads win (1080p: 0.72 -> 0.57 ms per 64 frames, 4K: 1.27 -> 0.50 ms per 32 frames)
+  const char *force = getenv("ORBGPU_QT_THREADS");  // tuning aid: 256 or 1024
+  const bool big = force ? atoi(force) > 256 : (long long)g.lv[0].w * g.lv[0].h > 1024 * 768;
+  const void *fn = big ? reinterpret_cast<const void *>(k_quadtree<1024>) : reinterpret_cast<const void *>(k_quadtree<256>);
+  static size_t configured[2] = {0, 0};
+  if (lds > 64 * 1024 && lds > configured[big]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    configured[big] = lds;
   }
   a.prof = nullptr;
   const bool profile = getenv("ORBGPU_QT_PROFILE") != nullptr;
   if (profile && hipMalloc(&a.prof, 64 * 8) == hipSuccess) (void)hipMemset(a.prof, 0, 64 * 8);
-  hipLaunchKernelGGL(k_quadtree, dim3(g.levels, n_frames), dim3(QT_THREADS), lds, c->stream, g, a);
+  if (big)
+    hipLaunchKernelGGL(k_quadtree<1024>, dim3(g.levels, n_frames), dim3(1024), lds, c->stream, g, a);
+  else
+    hipLaunchKernelGGL(k_quadtree<256>, dim3(g.levels, n_frames), dim3(256), lds, c->stream, g, a);
   if (a.prof) {  // debugging aid: synchronous, prints the phase times of one workgroup
     unsigned long long h[64];
     (void)hipDeviceSynchronize();
