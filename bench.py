@@ -198,6 +198,7 @@ def main():
     A = 5 * P - g.w[0] * g.h[0] - g.w[g.levels - 1] * g.h[g.levels - 1] + 1978 * NF
     ext_s = st[6] * 1e-3
     pipeline = {"algorithmic_bytes_per_frame": A, "extract_ms_per_batch": round(st[6], 3),
+                "extract_only_frames_per_s": round(B / ext_s, 1) if ext_s > 0 else 0.0,
                 "achieved_GBps": round(A * B / ext_s / 1e9, 2) if ext_s > 0 else 0.0,
                 "frac_of_8TBps": round(A * B / ext_s / 1e9 / hbm_peak, 5) if ext_s > 0 else 0.0,
                 "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast_score", "cells", "quadtree", "blur", "orient_describe"), st[:6])},
