@@ -260,8 +260,8 @@ def main():
     database = {}
     if not args.no_database:
         # place recognition (DBoW2Database::DetectNBestCandidates' query half): one BowVector against 20,000 resident
-        # keyframe BowVectors of 800 words each out of a 100k-word vocabulary; algorithmic bytes = every (word, value)
-        # of the database read once = 12 B per entry
+        # keyframe BowVectors of 800 words each out of a 100k-word vocabulary; algorithmic bytes = every word id of the
+        # database read once (4 B per entry) + the value of every word the query shares (8 B)
         from orb_slam3_amd import _lib as L
         import ctypes as C
         K, WPK, VOC = 20_000, 800, 100_000
@@ -285,7 +285,7 @@ def main():
             check(lib.orbgpu_synchronize(fe.handle))
             times.append(time.perf_counter() - t1)
         q_s = min(times[1:])
-        db_bytes = K * WPK * 12
+        db_bytes = K * WPK * 4 + int(t_sh.sum().item()) * 8
         database = {"keyframes": K, "words_per_keyframe": WPK, "query_ms": round(q_s * 1e3, 4),
                     "keyframes_per_s": round(K / q_s, 1), "achieved_GBps": round(db_bytes / q_s / 1e9, 2),
                     "frac_of_8TBps": round(db_bytes / q_s / 1e9 / hbm_peak, 5),

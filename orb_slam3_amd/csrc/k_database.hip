@@ -9,13 +9,15 @@
 // lists that accumulates one double per common word IN WORD ORDER.  (KLScoring, :175-221, also sums over the words
 // only the query holds and goes through log(); it is not offered.)
 // Here the database is held keyframe-major (the transpose of the inverted file): one wave per keyframe, 64 of its
-// words per step, each lane looks its word up in the query (binary search in LDS), and the per-word terms are added
+// words per step, each lane looks its word up in the query (a 128 Kbit membership filter in LDS answers "not in the
+// query" with one read for almost every word; the rest take a binary search in LDS), and the per-word terms are added
 // to the running double strictly in word order (ballot + readlane), so the sum is the reference's bit for bit.
 #include "orbgpu_internal.h"
 
 namespace {
 
 constexpr int BS_WAVES = 4;
+constexpr int BS_FILTER_DW = 4096;  // membership filter: bit (word id mod 2^17) -- word ids are dense small integers
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
@@ -26,9 +28,16 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 template <bool Q_LDS>
 __global__ __launch_bounds__(64 * BS_WAVES) void k_bow_score(BowScoreDev a, unsigned long long *__restrict__ shared_out,
                                                              double *__restrict__ score_out) {
-  extern __shared__ unsigned s_qw[];  // the query's word ids (Q_LDS only)
+  extern __shared__ unsigned s_dyn[];  // Q_LDS: membership filter, then the query's word ids
+  unsigned *s_filter = s_dyn, *s_qw = s_dyn + BS_FILTER_DW;
   if (Q_LDS) {
-    for (int i = threadIdx.x; i < a.n_q; i += 64 * BS_WAVES) s_qw[i] = a.q_words[i];
+    for (int i = threadIdx.x; i < BS_FILTER_DW; i += 64 * BS_WAVES) s_filter[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.n_q; i += 64 * BS_WAVES) {
+      const unsigned w = a.q_words[i];
+      s_qw[i] = w;
+      atomicOr(&s_filter[(w >> 5) & (BS_FILTER_DW - 1)], 1u << (w & 31));
+    }
     __syncthreads();
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -37,36 +46,49 @@ __global__ __launch_bounds__(64 * BS_WAVES) void k_bow_score(BowScoreDev a, unsi
   const long long beg = a.kf_beg[k], end = a.kf_end[k];
   double acc = 0.0;
   unsigned long long sh = 0;
-  for (long long base = beg; base < end; base += 64) {
-    const long long i = base + lane;
-    bool hit = false;
-    double term = 0.0;
-    if (i < end) {
-      const unsigned w = a.kf_words[i];
-      int lo = 0, hi = a.n_q;  // std::map::lower_bound on the query
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const unsigned qw = Q_LDS ? s_qw[mid] : a.q_words[mid];
-        if (qw < w) lo = mid + 1; else hi = mid;
-      }
-      if (lo < a.n_q && (Q_LDS ? s_qw[lo] : a.q_words[lo]) == w) {
-        hit = true;
-        const double vi = a.q_values[lo], wi = a.kf_values[i];  // score(v1 = query, v2 = keyframe)
-        switch (a.scoring) {
-          case 0: term = (fabs(vi - wi) - fabs(vi)) - fabs(wi); break;       // L1_NORM, :41
-          case 2: hit = vi + wi != 0.0; term = vi * wi / (vi + wi); break;   // CHI_SQUARE, :148
-          case 4: term = sqrt(vi * wi); break;                               // BHATTACHARYYA, :245
-          default: term = vi * wi; break;                                    // L2_NORM :91, DOT_PRODUCT :290
-        }
-        const unsigned long long qc = a.q_counts ? a.q_counts[lo] : 1u, kc = a.kf_counts ? a.kf_counts[i] : 1u;
-        sh += kc * qc;
-      }
+  constexpr int U = 8;  // 64-word steps whose loads are in flight together (the loop is latency-bound otherwise)
+  for (long long base0 = beg; base0 < end; base0 += 64 * U) {
+    unsigned wv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long long i = base0 + 64 * u + lane;
+      wv[u] = i < end ? a.kf_words[i] : 0u;
     }
-    unsigned long long m = __ballot(hit);
-    while (m) {  // wave-uniform: common words in ascending order
-      const int b = __builtin_ctzll(m);
-      m &= m - 1;
-      acc += readlane_f64(term, b);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long long i = base0 + 64 * u + lane;
+      if (base0 + 64 * u >= end) break;  // wave-uniform
+      bool hit = false;
+      double term = 0.0;
+      if (i < end) {
+        const unsigned w = wv[u];
+        // the filter has no false negatives: a clear bit means the word is not in the query
+        const bool maybe = !Q_LDS || ((s_filter[(w >> 5) & (BS_FILTER_DW - 1)] >> (w & 31)) & 1u);
+        int lo = 0, hi = maybe ? a.n_q : 0;  // std::map::lower_bound on the query
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          const unsigned qw = Q_LDS ? s_qw[mid] : a.q_words[mid];
+          if (qw < w) lo = mid + 1; else hi = mid;
+        }
+        if (maybe && lo < a.n_q && (Q_LDS ? s_qw[lo] : a.q_words[lo]) == w) {
+          hit = true;
+          const double vi = a.q_values[lo], wi = a.kf_values[i];  // score(v1 = query, v2 = keyframe)
+          switch (a.scoring) {
+            case 0: term = (fabs(vi - wi) - fabs(vi)) - fabs(wi); break;       // L1_NORM, :41
+            case 2: hit = vi + wi != 0.0; term = vi * wi / (vi + wi); break;   // CHI_SQUARE, :148
+            case 4: term = sqrt(vi * wi); break;                               // BHATTACHARYYA, :245
+            default: term = vi * wi; break;                                    // L2_NORM :91, DOT_PRODUCT :290
+          }
+          const unsigned long long qc = a.q_counts ? a.q_counts[lo] : 1u, kc = a.kf_counts ? a.kf_counts[i] : 1u;
+          sh += kc * qc;
+        }
+      }
+      unsigned long long m = __ballot(hit);
+      while (m) {  // wave-uniform: common words in ascending order
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        acc += readlane_f64(term, b);
+      }
     }
   }
 #pragma unroll
@@ -103,7 +125,7 @@ __global__ __launch_bounds__(256) void k_bowdb_compact(const long long *__restri
 
 }  // namespace
 
-size_t bow_score_lds_bytes(int n_q) { return (size_t)n_q * 4 <= 48 * 1024 ? (size_t)std::max(n_q, 1) * 4 : 0; }
+size_t bow_score_lds_bytes(int n_q) { return (size_t)n_q * 4 <= 44 * 1024 ? (size_t)(BS_FILTER_DW + std::max(n_q, 1)) * 4 : 0; }
 
 void launch_bow_score(const orbgpu_ctx *c, const BowScoreDev &a, unsigned long long *d_shared, double *d_score) {
   const int grid = (a.n_keyframes + BS_WAVES - 1) / BS_WAVES;
