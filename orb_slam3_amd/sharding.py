@@ -46,15 +46,15 @@ def _needs_host_staging(t, group):
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def gather_keyframe_rows(tensors, group=None):
+def gather_keyframe_rows(tensors, group=None, _force_collective=False):
     """All-gather ragged per-keyframe shards.  tensors: sequence of [K_local, ...] tensors sharing K_local.
 
     Returns (gathered list of [K_total, ...], row_offset): this rank's keyframes are rows row_offset ..
     row_offset + K_local of the gathered set, in rank order (= sequence order for block sharding).
     One all_gather of the shard sizes, then one all_gather_into_tensor of equal-sized padded shards per tensor
-    (RCCL needs equal counts)."""
+    (RCCL needs equal counts).  _force_collective runs the collectives on a single rank too (a test of the backend)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (_force_collective and dist.is_initialized()):
         return list(tensors), 0
     rank = dist.get_rank(group)
     dev = tensors[0].device

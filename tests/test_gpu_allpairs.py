@@ -165,3 +165,32 @@ def test_allpairs_two_ranks_one_gpu(tmp_path):
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=110)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_gather_over_rccl_single_rank(tmp_path):
+    """The exchange step on the real backend: a one-rank "nccl" (= RCCL) group, initialised the way bench.py does it,
+    runs the all_gather / all_gather_into_tensor calls of gather_keyframe_rows on device tensors of the three dtypes
+    the path sends (uint8 records and descriptors, int32 counts).  More ranks need more GPUs than the test box has;
+    the multi-rank control flow is covered by the gloo tests."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, os.getcwd())\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "from orb_slam3_amd.sharding import gather_keyframe_rows\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "desc = torch.randint(0, 256, (5, 40, 32), dtype=torch.uint8, generator=g).cuda()\n"
+        "n = torch.randint(0, 41, (5,), dtype=torch.int32, generator=g).cuda()\n"
+        "(d2, n2), off = gather_keyframe_rows([desc, n], _force_collective=True)\n"
+        "assert off == 0 and torch.equal(d2, desc) and torch.equal(n2, n) and d2.is_cuda\n"
+        "t = torch.tensor([1.5], dtype=torch.float64, device='cuda'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()\n"
+        "assert t.item() == 1.5\n"
+        "dist.destroy_process_group()\n"
+        "print('rccl ok')\n")
+    root = str(__import__("pathlib").Path(__file__).resolve().parents[1])
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=100, cwd=root)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
