@@ -697,10 +697,10 @@ int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
   const char *force = getenv("ORBGPU_QT_THREADS");  // tuning aid: 256 or 1024
   const bool big = force ? atoi(force) > 256 : (long long)g.lv[0].w * g.lv[0].h > 1024 * 768;
   const void *fn = big ? reinterpret_cast<const void *>(k_quadtree<1024>) : reinterpret_cast<const void *>(k_quadtree<256>);
-  static size_t configured[2] = {0, 0};
-  if (lds > 64 * 1024 && lds > configured[big]) {
+  // the raised limit is a per-device property of the function: remembered per context (= per device)
+  if (lds > 64 * 1024 && lds > c->qt_lds_configured[big]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
-    configured[big] = lds;
+    c->qt_lds_configured[big] = lds;
   }
   a.prof = nullptr;
   const bool profile = getenv("ORBGPU_QT_PROFILE") != nullptr;

@@ -96,6 +96,7 @@ struct orbgpu_ctx {
   // device slabs, sized for max_batch frames
   uint8_t *d_pyr = nullptr, *d_score = nullptr, *d_blur = nullptr;
   Level0Src lvl0{nullptr, 0};     // where the last extract call's level 0 lives (kernel argument of that call)
+  mutable size_t qt_lds_configured[2] = {0, 0};  // dynamic-LDS limit already raised for k_quadtree<256> / <1024>
   bool no_zero_copy = false;      // ORBGPU_NO_ZERO_COPY=1: always copy level 0 into the slab (cross-check path)
   unsigned *d_nzmask = nullptr;   // [frame][mask_dwords_per_frame]: bit x of row y set iff score(x, y) != 0
   XTab *d_xtab = nullptr;
