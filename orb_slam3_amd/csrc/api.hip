@@ -409,6 +409,18 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   if (rc) return bail(rc);
   const DeviceGeom &g = ctx->geom;
   const size_t B = (size_t)params->max_batch;
+  if (!ctx->host_quadtree) {
+    // the quadtree kernel keeps a level's node list in LDS: about 2070 nodes fit the CU's 160 KB
+    int cap = 0, worst = 0;
+    for (int l = 0; l < g.levels; l++)
+      if (g.lv[l].kp_cap > cap) { cap = g.lv[l].kp_cap; worst = l; }
+    if (quadtree_lds_bytes((cap + 7) & ~7) > 160 * 1024) {
+      fail(ctx, ORBGPU_E_CAPACITY, "max_features gives level " + std::to_string(worst) + " a budget of about " +
+                                       std::to_string(cap) + " keypoints; the quadtree kernel holds at most 2060 per level "
+                                       "(use more levels or a smaller max_features)");
+      return bail(ORBGPU_E_CAPACITY);
+    }
+  }
   auto alloc_all = [&]() -> int {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));

@@ -147,3 +147,53 @@ def test_extract_parameter_sweep(oracle, w, h, nfeat, scale, levels, fi, fm, kin
     _kp_equal(ft.keypoints, okp)
     assert np.array_equal(ft.descriptors, odesc)
     fe.close()
+
+
+def _fuzz_case(seed):
+    """a random but reproducible constructor configuration whose top level still holds a 30-px FAST cell"""
+    rng = np.random.default_rng(seed)
+    w, h = int(rng.integers(150, 900)), int(rng.integers(150, 700))
+    if h > 2 * w:
+        h = 2 * w
+    scale = float(rng.choice([1.15, 1.2, 1.25, 1.33, 1.5, 1.7]))
+    levels = 1
+    while levels < 10 and min(w, h) / scale ** levels >= 70:
+        levels += 1
+    levels = int(rng.integers(1, levels + 1))
+    fm = int(rng.integers(3, 15))
+    fi = int(rng.integers(fm, 40))
+    nfeat = int(rng.integers(20, 2500))
+    kind = str(rng.choice(["rich", "rich", "low", "noise"]))
+    return w, h, nfeat, scale, levels, fi, fm, kind
+
+
+@pytest.mark.parametrize("seed", list(range(100, 116)))
+def test_extract_random_configurations(oracle, seed):
+    """sixteen seeded random configurations (size, pyramid, thresholds, budget, scene) against the oracle"""
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    w, h, nfeat, scale, levels, fi, fm, kind = _fuzz_case(seed)
+    img = synth.frame(seed, h, w)
+    if kind == "low":
+        img = (img.astype(np.float32) * 0.12 + 100).astype(np.uint8)
+    elif kind == "noise":
+        img = np.random.default_rng(seed).integers(0, 256, (h, w), dtype=np.uint8)
+    cfg = (w, h, nfeat, scale, levels, fi, fm, kind)
+    p = oracle.params(w, h, scale, levels, fi, fm)
+    try:
+        okp, odesc = oracle.extract(p, img, nfeat)
+    except ValueError:
+        # a geometry the reference cannot run either (no quadtree root when the height is about twice the width):
+        # the library must refuse it at construction
+        from orb_slam3_amd._lib import OrbGpuError
+        with pytest.raises(OrbGpuError):
+            ORBFeatureExtractor(w, h, scale, levels, fi, fm, max_features=nfeat)
+        return
+    fe = ORBFeatureExtractor(w, h, scale, levels, fi, fm, max_features=nfeat)
+    ft = Features(w, h)
+    assert fe.Extract(img, ft, nfeat) == 0
+    assert ft.Size() == len(okp), cfg
+    for fld in ("x", "y", "level", "size"):
+        assert np.array_equal(ft.keypoints[fld], okp[fld]), (fld, cfg)
+    assert np.array_equal(ft.keypoints["angle"], okp["angle"].astype(np.float32)), cfg
+    assert np.array_equal(ft.descriptors, odesc), cfg
+    fe.close()
