@@ -47,9 +47,10 @@ typedef struct {
   int32_t fast_init, fast_min; /* init_threshold_FAST / min_threshold_FAST */
   int32_t device;              /* HIP device ordinal */
   int32_t max_batch;           /* frames per orbgpu_extract_batch* call (>= 1) */
-  int32_t max_features;        /* largest feature_count that will be requested per frame; the share of one level
-                                * (orb_feature_extractor.cpp:211-224) may not exceed about 2060 keypoints, e.g.
-                                * max_features <= about 9400 at 8 levels x 1.2, <= 2060 with a single level */
+  int32_t max_features;        /* largest feature_count that will be requested per frame.  When the share of one
+                                * level (orb_feature_extractor.cpp:211-224) exceeds about 2060 keypoints -- max_features
+                                * above about 9400 at 8 levels x 1.2, above 2060 with a single level -- the quadtree
+                                * kernel keeps its node lists in global scratch instead of LDS (same results, slower) */
 } orbgpu_params;
 
 /* features::KeyPoint (src/features/key_point.h:10-23) in wire form.  angle holds the float that

@@ -409,17 +409,19 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   if (rc) return bail(rc);
   const DeviceGeom &g = ctx->geom;
   const size_t B = (size_t)params->max_batch;
-  if (!ctx->host_quadtree) {
-    // the quadtree kernel keeps a level's node list in LDS: about 2070 nodes fit the CU's 160 KB
-    int cap = 0, worst = 0;
-    for (int l = 0; l < g.levels; l++)
-      if (g.lv[l].kp_cap > cap) { cap = g.lv[l].kp_cap; worst = l; }
-    if (quadtree_lds_bytes((cap + 7) & ~7) > 160 * 1024) {
-      fail(ctx, ORBGPU_E_CAPACITY, "max_features gives level " + std::to_string(worst) + " a budget of about " +
-                                       std::to_string(cap) + " keypoints; the quadtree kernel holds at most 2060 per level "
-                                       "(use more levels or a smaller max_features)");
+  // the quadtree kernel keeps a level's node list in LDS: about 2070 nodes fit the CU's 160 KB.  A context whose
+  // max_features budgets more than that to one level (thousands of keypoints on a single level) gets global scratch
+  // for the node lists instead
+  size_t qt_node_scratch = 0;
+  {
+    int cap = 0;
+    for (int l = 0; l < g.levels; l++) cap = std::max(cap, g.lv[l].kp_cap);
+    cap = (cap + 7) & ~7;
+    if (cap > 65528) {  // list positions are 16-bit
+      fail(ctx, ORBGPU_E_CAPACITY, "max_features budgets more than 65528 keypoints to one pyramid level");
       return bail(ORBGPU_E_CAPACITY);
     }
+    if (quadtree_lds_bytes(cap) > 160 * 1024) qt_node_scratch = quadtree_node_bytes(cap) * (size_t)g.levels * B;
   }
   auto alloc_all = [&]() -> int {
     HIP_TRY(hipSetDevice(ctx->device));
@@ -444,6 +446,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(dmalloc(&ctx->d_cands_packed, B * g.cands_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cands_tmp, B * g.cands_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cell_prefix, B * g.cells_per_frame));
+    if (qt_node_scratch) HIP_TRY(dmalloc(&ctx->d_qt_nodes, qt_node_scratch));
     HIP_TRY(dmalloc(&ctx->d_error_flag, 1));
     HIP_TRY(hipMemset(ctx->d_error_flag, 0, sizeof(int)));
     HIP_TRY(hmalloc(&ctx->h_error_flag, 1));
@@ -474,7 +477,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *dptrs[] = {ctx->d_nzmask, ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count,
-                   ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix,
+                   ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes,
                    ctx->d_error_flag};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);

@@ -329,6 +329,8 @@ struct QtArgs {
   short2 *kp_xy;               // [frame][kps_per_frame]
   int *kp_count;               // [frame][levels]
   int *error_flag;
+  unsigned char *node_scratch; // node arrays of the workgroups when they do not fit LDS (NODES_GLOBAL), node_bytes each
+  size_t node_bytes;
   unsigned long long *prof;    // ORBGPU_QT_PROFILE=1: wall-clock stamps of workgroup (level 0, frame 0), debugging aid
   int node_cap;                // LDS entries per list array
   int budget[ORBGPU_MAX_LEVELS];
@@ -601,7 +603,10 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
   if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[13] = Sz;
 }
 
-template <int NT>
+// NODES_GLOBAL: the per-level node list (cap entries of every array below) is too large for LDS -- a single level
+// budgeted more than about 2060 keypoints -- and lives in a per-workgroup slice of global scratch instead; all of a
+// workgroup's waves share one CU (one L1), and the barriers between the phases order the accesses
+template <int NT, bool NODES_GLOBAL>
 __global__ __launch_bounds__(NT) void k_quadtree(DeviceGeom g, QtArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ u64 wsum[(NT / 64)];
@@ -616,6 +621,7 @@ __global__ __launch_bounds__(NT) void k_quadtree(DeviceGeom g, QtArgs a) {
   QShared S;
   unsigned char *p = smem;
   unsigned *lds_keys = reinterpret_cast<unsigned *>(p); p += sizeof(unsigned) * 2 * QT_LDS_KEYS;
+  if (NODES_GLOBAL) p = a.node_scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.node_bytes;
   QNode *nodes0 = reinterpret_cast<QNode *>(p); p += sizeof(QNode) * cap;
   QNode *nodes1 = reinterpret_cast<QNode *>(p); p += sizeof(QNode) * cap;
   S.qc = reinterpret_cast<uint4 *>(p); p += sizeof(uint4) * cap;
@@ -666,9 +672,11 @@ __global__ __launch_bounds__(NT) void k_quadtree(DeviceGeom g, QtArgs a) {
 
 }  // namespace
 
-size_t quadtree_lds_bytes(int node_cap) {
-  return sizeof(unsigned) * 2 * QT_LDS_KEYS + (size_t)node_cap * (2 * sizeof(QNode) + sizeof(uint4) + 2 * sizeof(u64) + 3 * sizeof(unsigned short) + 1) + 64;
+size_t quadtree_node_bytes(int node_cap) {
+  const size_t b = (size_t)node_cap * (2 * sizeof(QNode) + sizeof(uint4) + 2 * sizeof(u64) + 3 * sizeof(unsigned short) + 1) + 64;
+  return (b + 255) & ~(size_t)255;
 }
+size_t quadtree_lds_bytes(int node_cap) { return sizeof(unsigned) * 2 * QT_LDS_KEYS + quadtree_node_bytes(node_cap); }
 
 int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
   const DeviceGeom &g = c->geom;
@@ -689,14 +697,21 @@ int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
   }
   cap = (cap + 7) & ~7;
   a.node_cap = cap;
-  const size_t lds = quadtree_lds_bytes(cap);
-  if (lds > 160 * 1024) return -1;
+  size_t lds = quadtree_lds_bytes(cap);
+  const bool nodes_global = lds > 160 * 1024;
+  if (nodes_global) {
+    if (!c->d_qt_nodes) return -1;  // orbgpu_create allocates it for such contexts
+    a.node_scratch = c->d_qt_nodes;
+    a.node_bytes = quadtree_node_bytes(cap);
+    lds = sizeof(unsigned) * 2 * QT_LDS_KEYS + 64;
+  }
   // a level of a VGA-class image holds a few thousand candidates: 256 threads keep its short dependent rounds cheap
   // (measured with 512: 0.15 -> 0.34 ms per 256-frame batch); from about a megapixel on a round moves tens of thousands
   // of keys and 1024 threads win (1080p: 0.72 -> 0.57 ms per 64 frames, 4K: 1.27 -> 0.50 ms per 32 frames)
   const char *force = getenv("ORBGPU_QT_THREADS");  // tuning aid: 256 or 1024
   const bool big = force ? atoi(force) > 256 : (long long)g.lv[0].w * g.lv[0].h > 1024 * 768;
-  const void *fn = big ? reinterpret_cast<const void *>(k_quadtree<1024>) : reinterpret_cast<const void *>(k_quadtree<256>);
+  const void *fn = nodes_global ? (big ? reinterpret_cast<const void *>(k_quadtree<1024, true>) : reinterpret_cast<const void *>(k_quadtree<256, true>))
+                                : (big ? reinterpret_cast<const void *>(k_quadtree<1024, false>) : reinterpret_cast<const void *>(k_quadtree<256, false>));
   // the raised limit is a per-device property of the function: remembered per context (= per device)
   if (lds > 64 * 1024 && lds > c->qt_lds_configured[big]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
@@ -705,10 +720,14 @@ int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
   a.prof = nullptr;
   const bool profile = getenv("ORBGPU_QT_PROFILE") != nullptr;
   if (profile && hipMalloc(&a.prof, 64 * 8) == hipSuccess) (void)hipMemset(a.prof, 0, 64 * 8);
-  if (big)
-    hipLaunchKernelGGL(k_quadtree<1024>, dim3(g.levels, n_frames), dim3(1024), lds, c->stream, g, a);
-  else
-    hipLaunchKernelGGL(k_quadtree<256>, dim3(g.levels, n_frames), dim3(256), lds, c->stream, g, a);
+  const dim3 grid(g.levels, n_frames);
+  if (nodes_global) {
+    if (big) hipLaunchKernelGGL((k_quadtree<1024, true>), grid, dim3(1024), lds, c->stream, g, a);
+    else hipLaunchKernelGGL((k_quadtree<256, true>), grid, dim3(256), lds, c->stream, g, a);
+  } else {
+    if (big) hipLaunchKernelGGL((k_quadtree<1024, false>), grid, dim3(1024), lds, c->stream, g, a);
+    else hipLaunchKernelGGL((k_quadtree<256, false>), grid, dim3(256), lds, c->stream, g, a);
+  }
   if (a.prof) {  // debugging aid: synchronous, prints the phase times of one workgroup
     unsigned long long h[64];
     (void)hipDeviceSynchronize();

@@ -106,6 +106,7 @@ struct orbgpu_ctx {
   unsigned *d_cands_packed = nullptr;  // dense copy for the host quadtree / key buffer A of the device quadtree
   unsigned *d_cands_tmp = nullptr;     // key buffer B of the device quadtree (levels too large for LDS)
   int *d_cell_prefix = nullptr;        // [frame][cells_per_frame]
+  unsigned char *d_qt_nodes = nullptr; // [frame][level] node arrays of the quadtree kernel when they do not fit LDS
   int *d_error_flag = nullptr;         // set by kernels on capacity violations
   int *h_error_flag = nullptr;
   bool host_quadtree = false;          // ORBGPU_HOST_QUADTREE=1: cross-check path (quadtree.cpp)
@@ -166,6 +167,7 @@ void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t fr
 // device quadtree (k_quadtree.hip); budget = per-level feature budget.  Returns 0 or -1 (LDS too large)
 int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget);
 size_t quadtree_lds_bytes(int node_cap);
+size_t quadtree_node_bytes(int node_cap);
 
 // host quadtree (DistributeOctTree), flat-array formulation; returns number of keypoints written
 int quadtree_distribute(const unsigned *cands, const CellEntry *cells, int n_cells, int w, int h, int n_features,

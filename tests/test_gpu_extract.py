@@ -120,6 +120,8 @@ def _scene(kind, seed, h, w):
         for _ in range(40):
             img[int(rng.integers(20, h - 20)), int(rng.integers(20, w - 20))] = 255
         return img
+    if kind == "noise":            # white noise: candidates everywhere
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
     return synth.frame(seed, h, w)
 
 
@@ -134,6 +136,8 @@ def _scene(kind, seed, h, w):
     (640, 480, 1000, 1.2, 8, 20, 7, "saturated", 48),
     (640, 480, 1000, 1.2, 8, 20, 7, "gradient", 49),
     (3840, 2160, 5000, 1.2, 8, 20, 7, "rich", 50),      # BASELINE.json configs[2], 4K
+    (640, 480, 3000, 1.2, 1, 12, 5, "rich", 51),        # 3000 keypoints on ONE level: quadtree node lists in global scratch
+    (1280, 960, 12000, 1.2, 2, 12, 5, "noise", 52),     # the same with 1024 threads and two levels
 ])
 def test_extract_parameter_sweep(oracle, w, h, nfeat, scale, levels, fi, fm, kind, seed):
     """other constructor arguments, image sizes and degenerate scenes: keypoints and descriptors against the oracle"""
