@@ -84,14 +84,16 @@ constexpr int PR = 19;              // patch radius staged for the descriptor (t
 constexpr int PW = 2 * PR + 1;      // 39 rows
 constexpr int PDW = 11;             // aligned dwords per staged row: 39 bytes + up to 3 bytes of misalignment
 constexpr int PPITCH = PDW * 4;     // 44
-constexpr int KPB = 8;              // waves per workgroup
-constexpr int KPW = 2;              // keypoints per wave, processed side by side so that twice as many loads are in flight
+constexpr int KPB = 4;              // waves per workgroup
+constexpr int KPW = 4;              // keypoints per wave, processed side by side: four times the loads in flight, and the
+                                    // pattern loads / address math shared (measured per 256-frame batch: 8 waves x 2:
+                                    // 0.256 ms, 4 x 4: 0.245, 2 x 4: 0.251, 6 x 4: 0.316, 8 x 4: 0.290)
 constexpr int KPG = KPB * KPW;      // keypoint slots per workgroup
 constexpr int PATCH_DW = PW * PDW + 11;
 
 // blockDim = 64 * KPB; 1-D grid over (slot group, frame) in XCD order.  The kernel is latency-bound (keypoint -> patch
 // -> orientation -> sin/cos -> taps is a chain of dependent memory round trips), so it is organised for loads in
-// flight, not for instruction count: a wave owns two keypoints, the blurred patches go straight from global memory
+// flight, not for instruction count: a wave owns four keypoints, the blurred patches go straight from global memory
 // to LDS (global_load_lds: no staging registers, 8 waves per SIMD), and everything that depends only on the slot is
 // forced wave-uniform (readfirstlane) so it runs on the scalar ALU.
 __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__restrict__ pyr,
@@ -216,7 +218,10 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
   __syncthreads();
   const int total = s_prefix[ORBGPU_MAX_LEVELS - 1];
   if (group == 0 && threadIdx.x == 0) out_n[f] = total;
-  if (total > capacity || !(valid[0] || valid[1])) return;
+  bool any_valid = false;
+#pragma unroll
+  for (int h = 0; h < KPW; h++) any_valid |= valid[h];
+  if (total > capacity || !any_valid) return;
   // the lane's 4 test patterns (pattern_, 16 bytes each), shared by the wave's two keypoints
   const float4 *pat = reinterpret_cast<const float4 *>(c_pattern.v);
   float4 ptn[4];
