@@ -153,7 +153,7 @@ int build_resize_tables(orbgpu_ctx *ctx, std::vector<XTab> &xt, std::vector<YTab
       Y.b0 = sat_short(cv_round_f((1.f - fy) * 2048.f));
       Y.b1 = sat_short(cv_round_f(fy * 2048.f));
     }
-    // LDS footprint of the largest 128 x 32 output tile of this level (k_resize_level stages exactly this)
+    // LDS footprint of the largest 128 x 64 output tile of this level (k_resize_level stages exactly this)
     const XTab *X = &xt[(size_t)g.lv[l].xtab_off];
     const YTab *Y = &yt[(size_t)g.lv[l].ytab_off];
     int cols = 0, rows = 0;
@@ -161,8 +161,8 @@ int build_resize_tables(orbgpu_ctx *ctx, std::vector<XTab> &xt, std::vector<YTab
       const int dx1 = std::min(dx0 + 128, dw) - 1;
       cols = std::max(cols, ((X[dx1].sx0 + 1 - (X[dx0].sx0 & ~15)) / 16 + 1) * 16);
     }
-    for (int dy0 = 0; dy0 < dh; dy0 += 32) {
-      const int dy1 = std::min(dy0 + 32, dh) - 1;
+    for (int dy0 = 0; dy0 < dh; dy0 += 64) {
+      const int dy1 = std::min(dy0 + 64, dh) - 1;
       rows = std::max(rows, Y[dy1].sy1 - Y[dy0].sy0 + 1);
     }
     ctx->rs_pitch[l] = cols;
