@@ -64,7 +64,7 @@ int build_geometry(orbgpu_ctx *ctx) {
   int budget[ORBGPU_MAX_LEVELS];
   level_budget(p.scale_factor, p.levels, p.max_features, budget);
   unsigned off = 0;
-  int cell_off = 0, cand_off = 0, kp_off = 0, ftile_off = 0, xt = 0, yt = 0, mask_off = 0;
+  int cell_off = 0, cand_off = 0, kp_off = 0, ftile_off = 0, btile_off = 0, xt = 0, yt = 0, mask_off = 0;
   for (int l = 0; l < p.levels; l++) {
     LevelGeom &L = g.lv[l];
     const float s = (float)ctx->inv_scale[l];  // :506-508
@@ -98,6 +98,8 @@ int build_geometry(orbgpu_ctx *ctx) {
     L.mask_off = mask_off;
     mask_off += L.mask_pitch * L.h;
     ftile_off += ((L.w + 127) / 128) * ((L.h + 31) / 32);
+    L.btile_off = btile_off;
+    btile_off += ((L.w + 127) / 128) * ((L.h + ORBGPU_BLUR_TILE_H - 1) / ORBGPU_BLUR_TILE_H);
     L.xtab_off = xt;
     L.ytab_off = yt;
     xt += L.w;
@@ -110,6 +112,7 @@ int build_geometry(orbgpu_ctx *ctx) {
   g.cands_per_frame = cand_off;
   g.kps_per_frame = kp_off;
   g.ftiles_per_frame = ftile_off;
+  g.btiles_per_frame = btile_off;
   for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) {
     g.kp_offs[l] = l < g.levels ? g.lv[l].kp_off : INT_MAX;
     g.ftile_offs[l] = l < g.levels ? g.lv[l].ftile_off : INT_MAX;
@@ -421,7 +424,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       fail(ctx, ORBGPU_E_CAPACITY, "max_features budgets more than 65528 keypoints to one pyramid level");
       return bail(ORBGPU_E_CAPACITY);
     }
-    if (quadtree_lds_bytes(cap) > 160 * 1024) qt_node_scratch = quadtree_node_bytes(cap) * (size_t)g.levels * B;
+    if (quadtree_lds_bytes(cap) > ORBGPU_QT_LDS_LIMIT) qt_node_scratch = quadtree_node_bytes(cap) * (size_t)g.levels * B;
   }
   auto alloc_all = [&]() -> int {
     HIP_TRY(hipSetDevice(ctx->device));

@@ -149,13 +149,13 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 // Gaussian blur 7x7, sigma 2, BORDER_REFLECT_101 -- OpenCV's 8.8 fixed-point path:
 //   h = sum k_i * src[x+i-3]            (u16, <= 65280)
 //   dst = (sum k_j * h[y+j-3] + 32768) >> 16
-// One launch covers all levels of all frames.  Tile 128 x 32, apron 3 rows / 4 columns, both passes in LDS and in
+// One launch covers all levels of all frames.  Tile 128 x 40, apron 3 rows / 4 columns, both passes in LDS and in
 // packed integer math (the integer VALU, not HBM, is what bounds this kernel):
 //   horizontal: per pixel two byte-aligned dwords of the row (v_alignbyte_b32) and two v_dot4_u32_u8 against the
 //               kernel bytes; two rows per lane are interleaved so that LDS holds (row 2m, row 2m+1) pairs per pixel;
 //   vertical:   four v_dot2_u32_u16 per pixel on those row pairs (weights chosen by the parity of the output row).
-constexpr int BT_H = 32;
-constexpr int BT_ROWS = BT_H + 6;        // 38 staged rows = 19 row pairs
+constexpr int BT_H = ORBGPU_BLUR_TILE_H;
+constexpr int BT_ROWS = BT_H + 6;        // 46 staged rows = 23 row pairs
 constexpr int BT_PAIRS = BT_ROWS / 2;
 
 typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
@@ -179,11 +179,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   __shared__ __attribute__((aligned(16))) unsigned hbuf[BT_PAIRS * TILE_W];  // (h[2m][x], h[2m+1][x]) per dword
   // tile -> (level, tile x, tile y)
   int t, frame, l = 0;
-  if (!xcd_item_frame(g.ftiles_per_frame, n_frames, t, frame)) return;
+  if (!xcd_item_frame(g.btiles_per_frame, n_frames, t, frame)) return;
 #pragma unroll 1
-  while (l + 1 < g.levels && t >= g.lv[l + 1].ftile_off) l++;
+  while (l + 1 < g.levels && t >= g.lv[l + 1].btile_off) l++;
   const LevelGeom L = g.lv[l];
-  t -= L.ftile_off;
+  t -= L.btile_off;
   const int tiles_x = (L.w + TILE_W - 1) / TILE_W;
   const int x0 = (t % tiles_x) * TILE_W, y0 = (t / tiles_x) * BT_H;
   const size_t base = (size_t)frame * g.frame_bytes + L.off;
@@ -270,6 +270,6 @@ void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level) {
 }
 
 void launch_blur(const orbgpu_ctx *c, int n_frames, hipStream_t stream) {
-  dim3 grid(c->geom.ftiles_per_frame * xcd_frames(n_frames));
+  dim3 grid(c->geom.btiles_per_frame * xcd_frames(n_frames));
   hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, stream, c->d_pyr, c->d_blur, c->geom, n_frames, c->lvl0);
 }

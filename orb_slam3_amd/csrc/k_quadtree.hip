@@ -698,7 +698,7 @@ int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
   cap = (cap + 7) & ~7;
   a.node_cap = cap;
   size_t lds = quadtree_lds_bytes(cap);
-  const bool nodes_global = lds > 160 * 1024;
+  const bool nodes_global = lds > ORBGPU_QT_LDS_LIMIT;
   if (nodes_global) {
     if (!c->d_qt_nodes) return -1;  // orbgpu_create allocates it for such contexts
     a.node_scratch = c->d_qt_nodes;

@@ -19,6 +19,10 @@
 
 // One pyramid level as the kernels see it.  All images of a frame (pyramid, score, blurred) share
 // this layout: level l starts `off` bytes into the frame slab, rows are `pitch` bytes apart.
+// rows per blur tile: fewer apron rows per output row than 32, still 8 workgroups per CU (measured per 256-frame
+// batch: 32 rows 0.286 ms, 40: 0.275, 48: 0.277, 56: 0.293, 64: 0.319)
+constexpr int ORBGPU_BLUR_TILE_H = 40;
+
 struct LevelGeom {
   int w, h, pitch;
   unsigned off;
@@ -26,7 +30,8 @@ struct LevelGeom {
   int cell_off;                    // first cell of this level in a frame's cell table
   int cand_off, cand_cap;          // candidate sub-pool (u32 entries) inside a frame's candidate slab
   int kp_off, kp_cap;              // keypoint slots of this level inside a frame's keypoint slab
-  int ftile_off;                   // first 128x32 tile of this level in the all-level tile index (FAST, blur)
+  int ftile_off;                   // first 128x32 tile of this level in the all-level tile index (FAST)
+  int btile_off;                   // first tile of this level in the blur kernel's tile index (128 x ORBGPU_BLUR_TILE_H)
   int mask_off, mask_pitch;        // non-zero-score bit plane: first dword of the level, dwords per row
   int xtab_off, ytab_off;          // resize coefficient tables (entries)
   int kp_size;                     // int(31 * scale_factors_[l])
@@ -41,6 +46,7 @@ struct DeviceGeom {
   int cands_per_frame;
   int kps_per_frame;      // sum of kp_cap
   int ftiles_per_frame;
+  int btiles_per_frame;
   int mask_dwords_per_frame;
   // compact copies of the per-level offsets (INT_MAX beyond the last level): one wide scalar load finds a level
   int kp_offs[ORBGPU_MAX_LEVELS], ftile_offs[ORBGPU_MAX_LEVELS], cell_offs[ORBGPU_MAX_LEVELS];
@@ -167,6 +173,8 @@ void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t fr
 // device quadtree (k_quadtree.hip); budget = per-level feature budget.  Returns 0 or -1 (LDS too large)
 int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget);
 size_t quadtree_lds_bytes(int node_cap);
+// dynamic LDS the quadtree kernel may ask for: the CU's 160 KB less its static arrays (scan sums, partition counters)
+constexpr size_t ORBGPU_QT_LDS_LIMIT = 156 * 1024;
 size_t quadtree_node_bytes(int node_cap);
 
 // host quadtree (DistributeOctTree), flat-array formulation; returns number of keypoints written

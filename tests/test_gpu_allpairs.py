@@ -104,7 +104,9 @@ import numpy as np, torch, torch.distributed as dist
 from orb_slam3_amd import synth, _lib
 from orb_slam3_amd.features import ORBFeatureExtractor
 from orb_slam3_amd.sharding import frame_block, keyframe_ids, match_keyframes_allpairs
-dist.init_process_group("gloo")      # two ranks share the one GPU of the test box; RCCL needs one GPU per rank
+# two ranks share the one GPU of the test box; RCCL needs one GPU per rank.  File rendezvous: no fixed port to collide on
+dist.init_process_group("gloo", init_method="file://" + os.environ["RDZV_FILE"], rank=int(os.environ["RANK"]),
+                        world_size=int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
 W, H, NF, n_frames, every = 320, 240, 300, 14, 2
 dev = torch.device("cuda", 0)
@@ -151,16 +153,12 @@ print("rank", rank, "ok", int(tot))
 def test_allpairs_two_ranks_one_gpu(tmp_path):
     """Frame-sharded extraction + ONE all-gather + row-sharded all-pairs matching on two ranks equals the
     single-process result (gloo rendezvous; both ranks use the test box's single GPU)."""
-    import os, socket, subprocess, sys
+    import os, subprocess, sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
     script = tmp_path / "rank_worker.py"
     script.write_text(_RANK_WORKER.format(root=str(root)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    env = dict(os.environ, RDZV_FILE=str(tmp_path / "rendezvous"), WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=110)[0].decode() for p in procs]
@@ -169,6 +167,7 @@ def test_allpairs_two_ranks_one_gpu(tmp_path):
 
 def test_gather_over_rccl_single_rank(tmp_path):
     """The exchange step on the real backend: a one-rank "nccl" (= RCCL) group, initialised the way bench.py does it,
+    (file rendezvous here)
     runs the all_gather / all_gather_into_tensor calls of gather_keyframe_rows on device tensors of the three dtypes
     the path sends (uint8 records and descriptors, int32 counts).  More ranks need more GPUs than the test box has;
     the multi-rank control flow is covered by the gloo tests."""
@@ -178,9 +177,8 @@ def test_gather_over_rccl_single_rank(tmp_path):
     script.write_text(
         "import os, sys, torch, torch.distributed as dist\n"
         "sys.path.insert(0, os.getcwd())\n"
-        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')\n"
         "torch.cuda.set_device(0)\n"
-        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "dist.init_process_group('nccl', init_method='file://' + sys.argv[1], rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
         "from orb_slam3_amd.sharding import gather_keyframe_rows\n"
         "g = torch.Generator().manual_seed(3)\n"
         "desc = torch.randint(0, 256, (5, 40, 32), dtype=torch.uint8, generator=g).cuda()\n"
@@ -192,5 +190,5 @@ def test_gather_over_rccl_single_rank(tmp_path):
         "dist.destroy_process_group()\n"
         "print('rccl ok')\n")
     root = str(__import__("pathlib").Path(__file__).resolve().parents[1])
-    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=100, cwd=root)
+    out = subprocess.run([sys.executable, str(script), str(tmp_path / "rendezvous")], capture_output=True, text=True, timeout=100, cwd=root)
     assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]

@@ -138,6 +138,8 @@ def _scene(kind, seed, h, w):
     (3840, 2160, 5000, 1.2, 8, 20, 7, "rich", 50),      # BASELINE.json configs[2], 4K
     (640, 480, 3000, 1.2, 1, 12, 5, "rich", 51),        # 3000 keypoints on ONE level: quadtree node lists in global scratch
     (1280, 960, 12000, 1.2, 2, 12, 5, "noise", 52),     # the same with 1024 threads and two levels
+    (640, 480, 1960, 1.2, 1, 12, 5, "noise", 53),       # node lists just below the LDS limit (about 154 KB of dynamic LDS)
+    (640, 480, 2040, 1.2, 1, 12, 5, "noise", 54),       # ... and just above it
 ])
 def test_extract_parameter_sweep(oracle, w, h, nfeat, scale, levels, fi, fm, kind, seed):
     """other constructor arguments, image sizes and degenerate scenes: keypoints and descriptors against the oracle"""

@@ -2,7 +2,6 @@
 interface mirror keeps the reference's names, and the frame-sharding / all-gather plumbing works on 2 gloo ranks."""
 import os
 import re
-import socket
 import subprocess
 import sys
 from pathlib import Path
@@ -75,7 +74,8 @@ import os, sys
 sys.path.insert(0, {root!r})
 import torch, torch.distributed as dist
 from orb_slam3_amd.sharding import frame_block, keyframe_ids, gather_keyframe_descriptors, allpairs_plan
-dist.init_process_group("gloo")
+dist.init_process_group("gloo", init_method="file://" + os.environ["RDZV_FILE"], rank=int(os.environ["RANK"]),
+                        world_size=int(os.environ["WORLD_SIZE"]))   # file rendezvous: no port to collide on
 rank, world = dist.get_rank(), dist.get_world_size()
 n_frames, every, cap = 47, 5, 6
 blk = frame_block(n_frames, world, rank)
@@ -98,11 +98,7 @@ print("rank", rank, "ok")
 def test_allgather_two_ranks_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=str(ROOT)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    env = dict(os.environ, RDZV_FILE=str(tmp_path / "rendezvous"), WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
