@@ -84,7 +84,9 @@ void orbgpu_destroy(orbgpu_ctx *ctx);
 /* message of the last failing call on this context (or of a failed orbgpu_create when ctx == NULL) */
 const char *orbgpu_last_error(const orbgpu_ctx *ctx);
 int orbgpu_get_geometry(const orbgpu_ctx *ctx, int32_t feature_count, orbgpu_geometry *out);
-/* the context's HIP stream (hipStream_t) so callers can order their own device work */
+/* The context enqueues all its work on a stream of its own (a hipStream_t, returned here).  Device buffers that the
+ * caller fills or reads on another stream (torch's, say) must be ordered against it: synchronise that stream before a
+ * *_device call, and orbgpu_synchronize (or an event on this stream) before reading the results. */
 void *orbgpu_stream(orbgpu_ctx *ctx);
 int orbgpu_synchronize(orbgpu_ctx *ctx);
 

@@ -24,6 +24,7 @@ def test_batch_device_extract_and_link(oracle, W, H, NF, B):
     d_kp = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()         # the fills run on torch's stream, the library on its own
     rc = lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr(), W * H, W, B, NF, d_kp.data_ptr(),
                                          d_desc.data_ptr(), cap, d_n.data_ptr())
     assert rc == 0, lib.orbgpu_last_error(fe.handle)
@@ -33,6 +34,7 @@ def test_batch_device_extract_and_link(oracle, W, H, NF, B):
     d_m = torch.zeros((npairs, cap), dtype=torch.int32, device=dev)
     d_d = torch.zeros((npairs, cap), dtype=torch.int32, device=dev)
     d_nm = torch.zeros(npairs, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     for check_orientation in (0, 1):
         rc = lib.orbgpu_match_frames_device(fe.handle, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
                                             to.data_ptr(), frm.data_ptr(), npairs, 100, 50, 0.9, check_orientation,
@@ -91,6 +93,7 @@ def test_batch_device_layouts(oracle, W, H, row_stride, base_off, frame_pad, in_
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros(B, dtype=torch.int32, device=dev)
     assert (d_imgs.data_ptr() % 256) == 0
+    torch.cuda.synchronize()         # the fills run on torch's stream, the library on its own
     rc = lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr() + base_off, frame_stride, row_stride, B, NF,
                                          d_kp.data_ptr(), d_desc.data_ptr(), cap, d_n.data_ptr())
     assert rc == 0, lib.orbgpu_last_error(fe.handle)

@@ -27,6 +27,7 @@ for B, W, H, NF, L in [(1, 320, 240, 300, 4), (7, 320, 240, 300, 4), (8, 336, 25
     d_kp = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()                                  # the fills run on torch's stream, the library on its own
     for rep in range(2):                                      # twice: the second call reuses every buffer
         assert lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr(), W * H, W, B, NF, d_kp.data_ptr(), d_desc.data_ptr(), cap,
                                                d_n.data_ptr()) == 0
@@ -36,6 +37,7 @@ for B, W, H, NF, L in [(1, 320, 240, 300, 4), (7, 320, 240, 300, 4), (8, 336, 25
     d_m = torch.zeros((npairs, cap), dtype=torch.int32, device=dev)
     d_d = torch.zeros((npairs, cap), dtype=torch.int32, device=dev)
     d_nm = torch.zeros(npairs, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     assert lib.orbgpu_match_frames_device(fe.handle, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap, to.data_ptr(), frm.data_ptr(),
                                           npairs, 100, 50, 0.9, 1, d_m.data_ptr(), d_d.data_ptr(), d_nm.data_ptr()) == 0
     assert lib.orbgpu_synchronize(fe.handle) == 0
