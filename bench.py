@@ -203,6 +203,15 @@ def main():
                 "frac_of_8TBps": round(A * B / ext_s / 1e9 / hbm_peak, 5) if ext_s > 0 else 0.0,
                 "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast_score", "cells", "quadtree", "blur", "orient_describe"), st[:6])},
                 "link_match_ms_per_batch": round(link_ms, 3)}
+    # SURVEY 8d's decomposition of A per stage, each against its own stage time (cells / quadtree have no
+    # algorithmic bytes of their own: their traffic is implementation intermediates)
+    px0, px7 = g.w[0] * g.h[0], g.w[g.levels - 1] * g.h[g.levels - 1]
+    stage_bytes = {"pyramid": 2 * P - px0 - px7, "fast_score": P, "blur": 2 * P,
+                   "orient_describe": (2 * 961 + 56) * NF}
+    pipeline["stage_algorithmic_GBps"] = {
+        k: round(stage_bytes[k] * B / (pipeline["stage_ms"][k] * 1e-3) / 1e9, 1) if pipeline["stage_ms"][k] > 0 else 0.0
+        for k in stage_bytes}
+    pipeline["stage_frac_of_8TBps"] = {k: round(v / hbm_peak, 4) for k, v in pipeline["stage_algorithmic_GBps"].items()}
 
     matching = {}
     if not args.no_bruteforce:
