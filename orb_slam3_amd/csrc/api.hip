@@ -210,76 +210,15 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
   return ms;
 }
 
-// Host cross-check path of the quadtree stage (ORBGPU_HOST_QUADTREE=1): candidates are packed and downloaded,
-// quadtree.cpp runs on a few host threads while the GPU blurs, keypoints are uploaded again.
-int host_quadtree_stage(orbgpu_ctx *ctx, int n_frames, const int *budget) {
-  const DeviceGeom &g = ctx->geom;
-  const int L = g.levels;
-  const int n_fl = n_frames * L;
-  // slow by design: the whole cell table and every candidate slot of the batch come down
-  const size_t total_cands = (size_t)n_frames * g.cands_per_frame;
-  if (total_cands > ctx->h_cands_cap) {
-    if (ctx->h_cands) HIP_TRY(hipHostFree(ctx->h_cands));
-    ctx->h_cands = nullptr;
-    ctx->h_cands_cap = 0;
-    HIP_TRY(hmalloc(&ctx->h_cands, total_cands));
-    ctx->h_cands_cap = total_cands;
-  }
-  HIP_TRY(hipMemcpyAsync(ctx->h_cells, ctx->d_cells, sizeof(CellEntry) * (size_t)n_frames * g.cells_per_frame,
-                         hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->h_cands, ctx->d_cands, sizeof(unsigned) * total_cands, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  const auto t0 = std::chrono::steady_clock::now();
-  {
-    const int n_tasks = n_fl;
-    std::atomic<int> next{0};
-    std::atomic<int> bad{0};
-    auto worker = [&]() {
-      for (;;) {
-        const int t = next.fetch_add(1);
-        if (t >= n_tasks) break;
-        const int f = t / L, l = t % L;
-        const LevelGeom &G = g.lv[l];
-        const int n = quadtree_distribute(ctx->h_cands + (size_t)f * g.cands_per_frame + G.cand_off,
-                                          ctx->h_cells + (size_t)f * g.cells_per_frame + G.cell_off, G.ncols * G.nrows,
-                                          G.w, G.h, budget[l], ctx->h_kp_xy + (size_t)f * g.kps_per_frame + G.kp_off,
-                                          G.kp_cap);
-        if (n < 0 || n > G.kp_cap) {
-          bad.store(1);
-          ctx->h_kp_count[t] = 0;
-        } else {
-          ctx->h_kp_count[t] = n;
-        }
-      }
-    };
-    int n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-    n_threads = std::min(n_threads, std::max(1, n_tasks / 4));
-    if (n_threads <= 1) {
-      worker();
-    } else {
-      std::vector<std::thread> pool;
-      for (int i = 0; i < n_threads; i++) pool.emplace_back(worker);
-      for (auto &th : pool) th.join();
-    }
-    if (bad.load()) return fail(ctx, ORBGPU_E_CAPACITY, "quadtree produced more keypoints than the level capacity");
-  }
-  ctx->quadtree_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  HIP_TRY(hipMemcpyAsync(ctx->d_kp_xy, ctx->h_kp_xy, sizeof(short2) * (size_t)n_frames * g.kps_per_frame,
-                         hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(ctx->d_kp_count, ctx->h_kp_count, sizeof(int) * n_fl, hipMemcpyHostToDevice, ctx->stream));
-  return 0;
-}
-
 // The whole extraction pipeline on device-resident level-0 images already imported into ctx->d_pyr.
-// Everything is enqueued on the context's stream; nothing here waits for the GPU unless the host cross-check
-// quadtree is selected.  Stage times and the device error flag are collected by finish_pipeline().
+// Everything is enqueued on the context's stream; nothing here waits for the GPU.  Stage times and the device
+// error flag are collected by finish_pipeline().
 int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                  int *d_n_out) {
   const DeviceGeom &g = ctx->geom;
   const int L = g.levels;
   int budget[ORBGPU_MAX_LEVELS];
   level_budget(ctx->params.scale_factor, L, feature_count, budget);
-  ctx->quadtree_host_ms = 0.f;
   // the device error flag is sticky: it is only cleared by finish_pipeline(), so queued calls cannot hide an error
   hipEvent_t *ev = ctx->ev[ctx->ev_head];
   HIP_TRY(hipEventRecord(ev[0], ctx->stream));
@@ -292,20 +231,13 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
   // dependent rounds in 8 x n_frames workgroups and leaves most of the chip idle
   // (enqueued after the quadtree so that the quadtree's workgroups are placed first and the blur fills the rest)
-  if (!ctx->host_quadtree) {
-    if (launch_quadtree(ctx, n_frames, budget) != 0)
-      return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
-    HIP_TRY(hipEventRecord(ev[4], ctx->stream));
-  }
+  if (launch_quadtree(ctx, n_frames, budget) != 0)
+    return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
+  HIP_TRY(hipEventRecord(ev[4], ctx->stream));
   HIP_TRY(hipStreamWaitEvent(ctx->stream_blur, ev[3], 0));
   HIP_TRY(hipEventRecord(ev[7], ctx->stream_blur));
   launch_blur(ctx, n_frames, ctx->stream_blur);
   HIP_TRY(hipEventRecord(ev[8], ctx->stream_blur));
-  if (ctx->host_quadtree) {
-    int rc = host_quadtree_stage(ctx, n_frames, budget);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[4], ctx->stream));
-  }
   HIP_TRY(hipStreamWaitEvent(ctx->stream, ev[8], 0));
   HIP_TRY(hipEventRecord(ev[5], ctx->stream));
   launch_orient_describe(ctx, n_frames, d_kp, d_desc, capacity, d_n_out);
@@ -335,7 +267,6 @@ int finish_pipeline(orbgpu_ctx *ctx) {
       acc[6] += elapsed(ev[0], ev[6]);
     }
     for (int i = 0; i < 7; i++) ctx->stage_ms[i] = acc[i] / (float)n;
-    if (ctx->host_quadtree) ctx->stage_ms[3] = ctx->quadtree_host_ms;
     if (*ctx->h_error_flag != 0) {
       const int code = *ctx->h_error_flag;
       *ctx->h_error_flag = 0;
@@ -394,8 +325,6 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   ctx->params = *params;
   ctx->device = params->device;
   {
-    const char *e = std::getenv("ORBGPU_HOST_QUADTREE");
-    ctx->host_quadtree = e && e[0] == '1';
     const char *z = std::getenv("ORBGPU_NO_ZERO_COPY");
     ctx->no_zero_copy = z && z[0] == '1';
   }
@@ -460,8 +389,6 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(dmalloc(&ctx->d_out_kp, B * ctx->out_capacity));
     HIP_TRY(dmalloc(&ctx->d_out_desc, B * ctx->out_capacity * 32));
     HIP_TRY(dmalloc(&ctx->d_out_n, B));
-    HIP_TRY(hmalloc(&ctx->h_cells, B * g.cells_per_frame));
-    HIP_TRY(hmalloc(&ctx->h_kp_xy, B * g.kps_per_frame));
     HIP_TRY(hmalloc(&ctx->h_kp_count, B * g.levels));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // xt/yt are stack-owned
     return 0;
@@ -484,7 +411,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
                    ctx->d_error_flag};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
-  void *hptrs[] = {ctx->h_cells, ctx->h_cands, ctx->h_kp_xy, ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};
+  void *hptrs[] = {ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};
   for (void *p : hptrs)
     if (p) (void)hipHostFree(p);
   for (auto &set : ctx->ev)

@@ -1,5 +1,5 @@
-// FAST-9/16 kernels: threshold-independent score map, per-cell NMS + threshold fallback + compaction,
-// and the dense re-pack of the candidate sub-pools that the host quadtree reads.  gfx950 only.
+// FAST-9/16 kernels: threshold-independent score map, per-cell NMS + threshold fallback + compaction.
+// gfx950 only.
 //
 // Reference stage: ComputeKeyPointsOctTree cell loop, src/features/orb_feature_extractor.cpp:227-276
 // (cv::FAST :259-266).  Closed form used:

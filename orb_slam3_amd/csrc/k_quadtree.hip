@@ -1,8 +1,8 @@
 // Quadtree keypoint distribution on the GPU: one workgroup per (frame, level).  gfx950 only.
 //
 // Reference stage: ORBFeatureExtractor::DistributeOctTree src/features/orb_feature_extractor.cpp:300-502 and
-// ExtractorNode::DivideNode :602-652.  Same formulation as the host version in quadtree.cpp (which stays as the
-// cross-check path): the std::list is an array in list order; every sweep rebuilds it as
+// ExtractorNode::DivideNode :602-652.  Flat-array formulation: the std::list is an array in list order; every sweep
+// rebuilds it as
 //     reverse(children in creation order) ++ (surviving old nodes in order),
 // keys of a node are a contiguous segment of a key buffer and a division is a stable 4-way partition of that
 // segment into the OTHER key buffer (segments of live nodes are disjoint, so nothing live is overwritten).

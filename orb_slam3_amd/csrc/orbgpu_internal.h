@@ -109,14 +109,12 @@ struct orbgpu_ctx {
   YTab *d_ytab = nullptr;
   CellEntry *d_cells = nullptr;   // [frame][cells_per_frame]
   unsigned *d_cands = nullptr;    // [frame][cands_per_frame]
-  unsigned *d_cands_packed = nullptr;  // dense copy for the host quadtree / key buffer A of the device quadtree
+  unsigned *d_cands_packed = nullptr;  // key buffer A of the quadtree kernel when its keys exceed LDS
   unsigned *d_cands_tmp = nullptr;     // key buffer B of the device quadtree (levels too large for LDS)
   int *d_cell_prefix = nullptr;        // [frame][cells_per_frame]
   unsigned char *d_qt_nodes = nullptr; // [frame][level] node arrays of the quadtree kernel when they do not fit LDS
   int *d_error_flag = nullptr;         // set by kernels on capacity violations
   int *h_error_flag = nullptr;
-  bool host_quadtree = false;          // ORBGPU_HOST_QUADTREE=1: cross-check path (quadtree.cpp)
-  float quadtree_host_ms = 0.f;
   short2 *d_kp_xy = nullptr;      // [frame][kps_per_frame] level coordinates after the quadtree
   int *d_kp_count = nullptr;      // [frame][levels]
   // internal outputs used by the host-pointer entry points
@@ -126,10 +124,6 @@ struct orbgpu_ctx {
   int out_capacity = 0;
 
   // pinned host staging
-  CellEntry *h_cells = nullptr;
-  unsigned *h_cands = nullptr;
-  size_t h_cands_cap = 0;
-  short2 *h_kp_xy = nullptr;
   int *h_kp_count = nullptr;
   uint8_t *h_imgs = nullptr;  // pinned upload buffer for host-pointer extraction
   uint8_t *h_out = nullptr;   // pinned download buffer of the batched host-pointer extraction: keypoints, then descriptors
@@ -177,9 +171,6 @@ size_t quadtree_lds_bytes(int node_cap);
 constexpr size_t ORBGPU_QT_LDS_LIMIT = 156 * 1024;
 size_t quadtree_node_bytes(int node_cap);
 
-// host quadtree (DistributeOctTree), flat-array formulation; returns number of keypoints written
-int quadtree_distribute(const unsigned *cands, const CellEntry *cells, int n_cells, int w, int h, int n_features,
-                        short2 *out_xy, int out_cap);
 
 // matching
 size_t match_scratch_size(int n_to, int n_from);

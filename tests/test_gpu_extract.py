@@ -86,23 +86,6 @@ def test_extract_quadtree_stress(oracle, w, h, nfeat, levels, seed, scene):
     fe.close()
 
 
-def test_host_quadtree_cross_check(oracle, monkeypatch):
-    """ORBGPU_HOST_QUADTREE=1 routes the quadtree stage through quadtree.cpp on the host; both paths must agree"""
-    from orb_slam3_amd.features import ORBFeatureExtractor, Features
-    img = synth.frame(31, 480, 640)
-    res = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("ORBGPU_HOST_QUADTREE", flag)
-        fe = ORBFeatureExtractor(640, 480, 1.2, 8, 20, 7, max_features=1000)
-        ft = Features(640, 480)
-        assert fe.Extract(img, ft, 1000) == 0
-        res.append(ft)
-        fe.close()
-    assert np.array_equal(res[0].keypoints, res[1].keypoints) and np.array_equal(res[0].descriptors, res[1].descriptors)
-    okp, odesc = oracle.extract_literal(oracle.params(640, 480), img, 1000)
-    _kp_equal(res[1].keypoints, okp)
-
-
 def _scene(kind, seed, h, w):
     rng = np.random.default_rng(seed)
     if kind == "checker":          # exact ties everywhere: equal scores, equal node sizes, equal responses
