@@ -284,15 +284,33 @@ __global__ __launch_bounds__(256) void k_link_partial(const orbgpu_keypoint *__r
   if (blockIdx.x * 256 >= n_to) return;
   const int j0 = blockIdx.y * chunk, j1 = min(j0 + chunk, n_from);
   const int ii = min(i, n_to - 1);
+  const orbgpu_keypoint *fk = kp + (size_t)ff * capacity;
+  const uint4 *fd = reinterpret_cast<const uint4 *>(desc + (size_t)ff * capacity * 32);
+  // AreaToIterator visits 'to' id 0 and the level-0 ids, AreaToPointee level-0 'from' only: a 'to' block or a 'from'
+  // chunk (chunk <= 256 = one id per thread) without any of them leaves empty partials.  The extractor packs its
+  // output by level, so all but a few blocks of a many-level frame pair end here
+  const bool to_live = i < n_to && (i == 0 || kp[(size_t)ft * capacity + ii].level == 0);
+  const bool from_live = j0 + (int)threadIdx.x < j1 && fk[j0 + threadIdx.x].level == 0;
+  const int any_to = __syncthreads_or(to_live), any_from = __syncthreads_or(from_live);
+  if (!any_to || !any_from) {
+    if (i < n_to) partial[((size_t)p * n_chunks + blockIdx.y) * capacity + i] = make_uint2(KEY_NONE, KEY_NONE);
+    return;
+  }
+  // only the few live blocks read the keypoint and its descriptor
   const orbgpu_keypoint k = kp[(size_t)ft * capacity + ii];
   const uint4 *td = reinterpret_cast<const uint4 *>(desc + ((size_t)ft * capacity + ii) * 32);
   const uint4 t0 = td[0], t1 = td[1];
   const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-  const orbgpu_keypoint *fk = kp + (size_t)ff * capacity;
-  const uint4 *fd = reinterpret_cast<const uint4 *>(desc + (size_t)ff * capacity * 32);
   unsigned best = KEY_NONE, second = KEY_NONE;
+  // a wave without a visited 'to' has nothing to scan (block 0 of a many-level frame: only id 0 is visited)
+  const int j_end = __ballot(to_live) ? j1 : j0;
 #pragma unroll 2
-  for (int j = j0; j < j1; j++) {
+  for (int j = j0; j < j_end; j++) {
+    // ListFeaturesInArea(point, window, 0, 0): level-0 'from' only (area_to_pointee.h:44-48); j is wave-uniform
+    if (fk[j].level != 0) continue;
+    // the window first: when no lane of the wave has this candidate in its window, the distance is not needed
+    const bool ok = to_live && fabs(fk[j].x - k.x) < window && fabs(fk[j].y - k.y) < window;
+    if (!__ballot(ok)) continue;
     const uint4 a = fd[2 * j], b = fd[2 * j + 1];
     unsigned d = __builtin_popcount(t[0] ^ a.x);
     d += __builtin_popcount(t[1] ^ a.y);
@@ -303,8 +321,6 @@ __global__ __launch_bounds__(256) void k_link_partial(const orbgpu_keypoint *__r
     d += __builtin_popcount(t[6] ^ b.z);
     d += __builtin_popcount(t[7] ^ b.w);
     unsigned key = (d << IDX_BITS) | (unsigned)j;
-    // ListFeaturesInArea(point, window, 0, 0): level-0 'from' only (area_to_pointee.h:44-48)
-    const bool ok = fk[j].level == 0 && fabs(fk[j].x - k.x) < window && fabs(fk[j].y - k.y) < window;
     key = ok ? key : KEY_NONE;
     second = umed3(best, key, second);
     best = min(best, key);
@@ -334,7 +350,10 @@ __global__ __launch_bounds__(256) void k_link_finalize(const orbgpu_keypoint *__
     }
     j = snn_accept(best, second, threshold, ratio, d);
     // AreaToIterator visits id 0 whatever its level, later ids only when level == 0 (area_to_iterator.h:24-43)
-    if (!(i == 0 || kp[(size_t)ft * capacity + i].level == 0)) j = -1;
+    if (!(i == 0 || kp[(size_t)ft * capacity + i].level == 0)) {
+      j = -1;
+      d = 0;
+    }
   }
   match[(size_t)p * capacity + i] = j;
   dist[(size_t)p * capacity + i] = d;
