@@ -296,22 +296,37 @@ __global__ __launch_bounds__(256) void k_link_partial(const orbgpu_keypoint *__r
     if (i < n_to) partial[((size_t)p * n_chunks + blockIdx.y) * capacity + i] = make_uint2(KEY_NONE, KEY_NONE);
     return;
   }
-  // only the few live blocks read the keypoint and its descriptor
+  // only the few live blocks read the keypoint and its descriptor; the chunk's 'from' entries go through LDS once
+  // (one per thread, coalesced) instead of being fetched by dependent scalar loads inside the scan
+  __shared__ double s_fx[256], s_fy[256];
+  __shared__ int s_lv[256];
+  __shared__ uint4 s_fd[512];
+  {
+    const int jt = j0 + (int)threadIdx.x;
+    if (jt < j1) {
+      s_fx[threadIdx.x] = fk[jt].x;
+      s_fy[threadIdx.x] = fk[jt].y;
+      s_lv[threadIdx.x] = fk[jt].level;
+      s_fd[2 * threadIdx.x] = fd[2 * jt];
+      s_fd[2 * threadIdx.x + 1] = fd[2 * jt + 1];
+    }
+  }
   const orbgpu_keypoint k = kp[(size_t)ft * capacity + ii];
   const uint4 *td = reinterpret_cast<const uint4 *>(desc + ((size_t)ft * capacity + ii) * 32);
   const uint4 t0 = td[0], t1 = td[1];
   const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  __syncthreads();
   unsigned best = KEY_NONE, second = KEY_NONE;
   // a wave without a visited 'to' has nothing to scan (block 0 of a many-level frame: only id 0 is visited)
-  const int j_end = __ballot(to_live) ? j1 : j0;
+  const int n_scan = __ballot(to_live) ? j1 - j0 : 0;
 #pragma unroll 2
-  for (int j = j0; j < j_end; j++) {
-    // ListFeaturesInArea(point, window, 0, 0): level-0 'from' only (area_to_pointee.h:44-48); j is wave-uniform
-    if (fk[j].level != 0) continue;
+  for (int jj = 0; jj < n_scan; jj++) {
+    // ListFeaturesInArea(point, window, 0, 0): level-0 'from' only (area_to_pointee.h:44-48); jj is wave-uniform
+    if (s_lv[jj] != 0) continue;
     // the window first: when no lane of the wave has this candidate in its window, the distance is not needed
-    const bool ok = to_live && fabs(fk[j].x - k.x) < window && fabs(fk[j].y - k.y) < window;
+    const bool ok = to_live && fabs(s_fx[jj] - k.x) < window && fabs(s_fy[jj] - k.y) < window;
     if (!__ballot(ok)) continue;
-    const uint4 a = fd[2 * j], b = fd[2 * j + 1];
+    const uint4 a = s_fd[2 * jj], b = s_fd[2 * jj + 1];
     unsigned d = __builtin_popcount(t[0] ^ a.x);
     d += __builtin_popcount(t[1] ^ a.y);
     d += __builtin_popcount(t[2] ^ a.z);
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(256) void k_link_partial(const orbgpu_keypoint *__r
     d += __builtin_popcount(t[5] ^ b.y);
     d += __builtin_popcount(t[6] ^ b.z);
     d += __builtin_popcount(t[7] ^ b.w);
-    unsigned key = (d << IDX_BITS) | (unsigned)j;
+    unsigned key = (d << IDX_BITS) | (unsigned)(j0 + jj);
     key = ok ? key : KEY_NONE;
     second = umed3(best, key, second);
     best = min(best, key);

@@ -64,6 +64,60 @@ def test_batch_device_extract_and_link(oracle, W, H, NF, B):
     fe.close()
 
 
+def test_link_keypoints_in_any_order(oracle):
+    """orbgpu_match_frames_device does not rely on the extractor's by-level packing: with the keypoints of both frames
+    shuffled (levels interleaved, so no block of the large-capacity path is skipped) it still gives the oracle's links."""
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    W, H, NF, B = 640, 480, 3000, 2
+    frames = synth.sequence(78, B, H, W)
+    fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_batch=B, max_features=NF)
+    cap = fe.geometry(NF).keypoint_capacity
+    p = oracle.params(W, H)
+    ok = [oracle.extract(p, frames[f], NF) for f in range(B)]
+    rng = np.random.default_rng(5)
+    kp = np.zeros((B, cap), _lib.KP_DTYPE)
+    desc = np.zeros((B, cap, 32), np.uint8)
+    n = np.zeros(B, np.int32)
+    shuffled = []
+    for f in range(B):
+        k, d = ok[f]
+        perm = rng.permutation(len(k))
+        k, d = k[perm], d[perm]
+        shuffled.append((k, d))
+        n[f] = len(k)
+        for name in ("x", "y", "level", "size"):
+            kp[f, :n[f]][name] = k[name]
+        kp[f, :n[f]]["angle"] = k["angle"].astype(np.float32)
+        desc[f, :n[f]] = d
+    dev = torch.device("cuda", 0)
+    d_kp = torch.from_numpy(kp.view(np.uint8).reshape(B, cap, -1)).to(dev)
+    d_desc = torch.from_numpy(desc).to(dev)
+    d_n = torch.from_numpy(n).to(dev)
+    to = torch.tensor([1, 0], dtype=torch.int32, device=dev)
+    frm = torch.tensor([0, 1], dtype=torch.int32, device=dev)
+    d_m = torch.zeros((2, cap), dtype=torch.int32, device=dev)
+    d_d = torch.zeros((2, cap), dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for check_orientation in (0, 1):
+        rc = lib.orbgpu_match_frames_device(fe.handle, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                                            to.data_ptr(), frm.data_ptr(), 2, 100, 50, 0.9, check_orientation,
+                                            d_m.data_ptr(), d_d.data_ptr(), d_nm.data_ptr())
+        assert rc == 0, lib.orbgpu_last_error(fe.handle)
+        assert lib.orbgpu_synchronize(fe.handle) == 0
+        m, nm = d_m.cpu().numpy(), d_nm.cpu().numpy()
+        for pi, (t, fr) in enumerate(((1, 0), (0, 1))):
+            mf, _ = oracle.match_area(shuffled[t][0], shuffled[t][1], shuffled[fr][0], shuffled[fr][1], 100, 50, 0.9)
+            if check_orientation:
+                mf, _ = oracle.orientation_validate(shuffled[t][0]["angle"], shuffled[fr][0]["angle"], mf)
+            assert np.array_equal(m[pi, :n[t]], mf), f"pair {pi}"
+            assert nm[pi] == (mf >= 0).sum() and nm[pi] > 0
+    fe.close()
+
+
 @pytest.mark.parametrize("W,H,row_stride,base_off,frame_pad,in_place", [
     (324, 244, 324, 0, 0, False),      # width not a multiple of 16, tight rows: level 0 is copied into the slab
     (324, 244, 336, 0, 64, True),      # rows padded to the slab pitch (pad bytes hold junk), gap between frames: read in place
