@@ -146,6 +146,17 @@ int orbgpu_match_bruteforce_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, in
                                    const uint8_t *d_from_desc, int32_t n_from, uint32_t threshold, double ratio,
                                    int32_t *d_from_idx_per_to, uint32_t *d_dist);
 
+/* No counterpart in the reference.  orbgpu_match_bruteforce_device for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same results,
+ * but its scratch (per-'from' claims and the per-chunk best / second partials) is a fixed 8 MiB __device__ array
+ * inside the library instead of the context's growable buffer, and the call performs no hipMalloc / hipFree.
+ * Limit: 8 * n_from (rounded up to 256) + 8 * n_to bytes must fit 8 MiB (ORBGPU_E_CAPACITY otherwise); the less room
+ * is left, the fewer 'from' chunks run side by side.  Every call on a GPU shares that GPU's array -- from any context or
+ * thread -- so calls that overlap on one GPU race: serialise them (one stream, or orbgpu_synchronize in between). */
+int orbgpu_match_bruteforce_noalloc_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, int32_t n_to,
+                                           const uint8_t *d_from_desc, int32_t n_from, uint32_t threshold, double ratio,
+                                           int32_t *d_from_idx_per_to, uint32_t *d_dist);
+
 /* replaces: the same matcher driven by AreaToIterator (iterators/area_to_iterator.h:16-58) or
  * ProjectionSearchIterator (iterators/projection_search_iterator.cpp:12-27): candidates of 'to' i are
  * the 'from' j (ascending j) with level in the range rule of Features::ListFeaturesInArea

@@ -66,7 +66,8 @@ assert KP_DTYPE.itemsize == 32
 # every symbol include/orbgpu.h declares (the inline orbgpu_hamming256 aside)
 EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_geometry", "orbgpu_stream",
            "orbgpu_synchronize", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
-           "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_window",
+           "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_bruteforce_noalloc_device",
+           "orbgpu_match_window",
            "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
            "orbgpu_match_allpairs_device", "orbgpu_vocab_create", "orbgpu_vocab_destroy", "orbgpu_bow_transform",
            "orbgpu_bow_transform_device", "orbgpu_distinctive_descriptor", "orbgpu_distinctive_descriptor_device",
@@ -102,6 +103,7 @@ def load():
         "orbgpu_debug_dump": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
         "orbgpu_match_bruteforce": (i32, [vp, vp, i32, vp, i32, u32, dbl, vp, vp]),
         "orbgpu_match_bruteforce_device": (i32, [vp, vp, i32, vp, i32, u32, dbl, vp, vp]),
+        "orbgpu_match_bruteforce_noalloc_device": (i32, [vp, vp, i32, vp, i32, u32, dbl, vp, vp]),
         "orbgpu_match_window": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_window_device": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_frames_device": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, u64, u32, dbl, i32, vp, vp, vp]),

@@ -357,6 +357,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   }
   auto alloc_all = [&]() -> int {
     HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(match_noalloc_init(ctx->device));  // address of this GPU's copy of the fixed scratch array
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_blur, hipStreamNonBlocking));
     for (auto &set : ctx->ev)
@@ -668,6 +669,37 @@ int orbgpu_match_bruteforce_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, in
   a.to_desc = d_to_desc; a.n_to = n_to; a.from_desc = d_from_desc; a.n_from = n_from;
   a.threshold = threshold; a.ratio = ratio;
   return match_device_locked(ctx, a, d_from_idx_per_to, d_dist);
+}
+
+int orbgpu_match_bruteforce_noalloc_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, int32_t n_to,
+                                           const uint8_t *d_from_desc, int32_t n_from, uint32_t threshold, double ratio,
+                                           int32_t *d_from_idx_per_to, uint32_t *d_dist) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (n_to < 0 || n_from < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if ((n_to > 0 && (!d_to_desc || !d_from_idx_per_to || !d_dist)) || (n_from > 0 && !d_from_desc))
+    return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (n_from >= (1 << 23)) return fail(ctx, ORBGPU_E_INVALID, "n_from must be below 2^23");
+  if (!(ratio >= 0.0)) return fail(ctx, ORBGPU_E_INVALID, "ratio must be >= 0");
+  if (n_to == 0) return ORBGPU_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n_from == 0) {
+    HIP_TRY(hipMemsetAsync(d_from_idx_per_to, 0xff, sizeof(int32_t) * (size_t)n_to, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_dist, 0, sizeof(uint32_t) * (size_t)n_to, ctx->stream));
+    return ORBGPU_OK;
+  }
+  const int max_chunks = match_noalloc_chunks(n_to, n_from);
+  if (max_chunks < 1)
+    return fail(ctx, ORBGPU_E_CAPACITY, "orbgpu_match_bruteforce_noalloc_device: 8 * (n_from + n_to) bytes exceed the fixed " +
+                                            std::to_string(ORBGPU_NOALLOC_SCRATCH_BYTES >> 20) + " MiB scratch");
+  void *scratch = match_noalloc_ptr(ctx->device);
+  if (!scratch) return fail(ctx, ORBGPU_E_HIP, "fixed scratch array was not resolved on this device");
+  orbgpu_window_args a{};
+  a.to_desc = d_to_desc; a.n_to = n_to; a.from_desc = d_from_desc; a.n_from = n_from;
+  a.threshold = threshold; a.ratio = ratio;
+  launch_match(ctx, a, d_from_idx_per_to, reinterpret_cast<unsigned *>(d_dist), scratch, max_chunks);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
 }
 
 int orbgpu_match_window_device(orbgpu_ctx *ctx, const orbgpu_window_args *a, int32_t *d_from_idx_per_to, uint32_t *d_dist) {

@@ -12,6 +12,8 @@
 // (popcount-accumulate) and three integer min/max on a packed (distance << 23 | index) key.  Because the
 // key orders by distance first and index second, "first candidate wins a tie" (strict < at :50) and
 // "a tie with the best becomes the second best" (:54) fall out of plain unsigned min / median.
+#include <climits>
+
 #include "orbgpu_internal.h"
 #include "tile_stage.hpp"
 
@@ -800,11 +802,11 @@ __global__ __launch_bounds__(256) void k_popcount_peak(unsigned *sink, int iters
 
 }  // namespace
 
-static int pick_chunks(int n_to, int n_from, int &chunk) {
+static int pick_chunks(int n_to, int n_from, int &chunk, int max_chunks = INT_MAX) {
   // enough waves to fill 256 CUs several times over, but chunks of at least 256 'from' rows
   const int to_waves = (n_to + 63) / 64;
   int want = (8192 + to_waves - 1) / to_waves;
-  int maxc = (n_from + 255) / 256;
+  int maxc = std::min((n_from + 255) / 256, max_chunks);
   int n_chunks = std::max(1, std::min(want, maxc));
   chunk = (n_from + n_chunks - 1) / n_chunks;
   n_chunks = (n_from + chunk - 1) / std::max(chunk, 1);
@@ -817,9 +819,10 @@ size_t match_scratch_size(int n_to, int n_from) {
   return (size_t)n_chunks * n_to * sizeof(uint2) + (size_t)n_from * sizeof(unsigned long long) + 256;
 }
 
-void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a, int *d_from_idx, unsigned *d_dist, void *scratch) {
+void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a, int *d_from_idx, unsigned *d_dist, void *scratch,
+                  int max_chunks) {
   int chunk;
-  const int n_chunks = pick_chunks(a.n_to, a.n_from, chunk);
+  const int n_chunks = pick_chunks(a.n_to, a.n_from, chunk, max_chunks);
   unsigned long long *claim = reinterpret_cast<unsigned long long *>(scratch);
   uint2 *partial = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(scratch) +
                                              (((size_t)a.n_from * sizeof(unsigned long long) + 255) & ~(size_t)255));
@@ -839,6 +842,39 @@ void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a, int *d_from_
                      a.to_active, th, a.ratio, d_from_idx, d_dist, claim);
   hipLaunchKernelGGL(k_snn_resolve, dim3((a.n_to + 255) / 256), dim3(256), 0, c->stream, a.n_to, d_from_idx, d_dist,
                      claim);
+}
+
+// ---- scratch of the entry point that allocates nothing (orbgpu_match_bruteforce_noalloc_device) --------------------
+// One array per GPU, inside the code object: claims [n_from] u64, then the (best, second) partials [chunks][n_to].
+// `scratch` is only a host-side handle of the symbol; the address on a device comes from hipGetSymbolAddress with
+// that device current (match_noalloc_init, called by orbgpu_create) and is what every launch and memset receives.
+static __device__ __align__(256) unsigned char scratch[ORBGPU_NOALLOC_SCRATCH_BYTES];
+static void *g_noalloc_ptr[ORBGPU_NOALLOC_MAX_DEVICES];
+static std::mutex g_noalloc_mu;
+
+hipError_t match_noalloc_init(int device) {
+  if (device < 0 || device >= ORBGPU_NOALLOC_MAX_DEVICES) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_noalloc_mu);
+  if (g_noalloc_ptr[device]) return hipSuccess;
+  void *p = nullptr;
+  const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));  // the caller made `device` current
+  if (e != hipSuccess) return e;
+  g_noalloc_ptr[device] = p;
+  return hipSuccess;
+}
+
+void *match_noalloc_ptr(int device) {
+  if (device < 0 || device >= ORBGPU_NOALLOC_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lock(g_noalloc_mu);
+  return g_noalloc_ptr[device];
+}
+
+// chunks of the 'from' range that fit the fixed scratch (0: not even one does)
+int match_noalloc_chunks(int n_to, int n_from) {
+  const size_t claim = ((size_t)n_from * sizeof(unsigned long long) + 255) & ~(size_t)255;
+  if (claim >= ORBGPU_NOALLOC_SCRATCH_BYTES) return 0;
+  const size_t fit = (ORBGPU_NOALLOC_SCRATCH_BYTES - claim) / ((size_t)n_to * sizeof(uint2));
+  return (int)std::min<size_t>(fit, 1u << 20);
 }
 
 size_t link_fused_lds_bytes(int capacity) { return (size_t)capacity * 24; }

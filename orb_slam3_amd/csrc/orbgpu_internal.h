@@ -174,8 +174,15 @@ size_t quadtree_node_bytes(int node_cap);
 
 // matching
 size_t match_scratch_size(int n_to, int n_from);
+// scratch holds match_scratch_size() bytes, or -- with max_chunks limiting the split of the 'from' range -- less
 void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a /* device pointers; to_xy==NULL => brute force */,
-                  int *d_from_idx, unsigned *d_dist, void *scratch);
+                  int *d_from_idx, unsigned *d_dist, void *scratch, int max_chunks = 0x7fffffff);
+// fixed per-GPU scratch of orbgpu_match_bruteforce_noalloc_device (a __device__ array in k_match.hip)
+constexpr size_t ORBGPU_NOALLOC_SCRATCH_BYTES = 8u << 20;
+constexpr int ORBGPU_NOALLOC_MAX_DEVICES = 64;
+hipError_t match_noalloc_init(int device);   // with `device` current; resolves the array's address on that GPU once
+void *match_noalloc_ptr(int device);
+int match_noalloc_chunks(int n_to, int n_from);
 void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const uint8_t *d_desc, const int *d_n,
                          int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
                          unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,
