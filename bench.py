@@ -23,6 +23,27 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks of this script (one per GPU) as child
+    processes -- before this process has touched torch or the GPU -- wait for them, and fail if any of them fails.
+    Rank 0 inherits stdout and prints the one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        raise SystemExit(f"bench.py: rank exit codes {codes}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,7 +61,15 @@ def main():
     ap.add_argument("--host-path", action="store_true",
                     help="also measure the PCIe-inclusive host-pointer entry points (off by default: their launches on 1 and "
                          "256 frames would be averaged into the per-kernel statistics of a profiled run)")
+    ap.add_argument("--no-large", action="store_true", help="skip the 1920x1080 / 3840x2160 section (BASELINE configs[2])")
+    ap.add_argument("--no-projection", action="store_true", help="skip the search-by-projection matching section")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous, barriers, the max-over-ranks reduction and the JSON line only (gloo, no GPU, no "
+                         "compute): the CPU test of the N-rank launch path.  Its line carries \"dry_run\": true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
@@ -52,6 +81,24 @@ def main():
     rehearsal = os.environ.get("ORB_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    if args.dry_run:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        seen = world
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seen = dist.get_world_size()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "world_size_observed": seen, "value": 0.0,
+                              "ms_per_step": round(float(t.item()) * 1e3, 3)}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -66,6 +113,7 @@ def main():
     from orb_slam3_amd.features import ORBFeatureExtractor
     lib = _lib.load()
     W, H, NF, B = args.width, args.height, args.features, args.frames
+    headline = (W, H, NF, B) == (640, 480, 1000, 256)
     fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, device=local_rank, max_batch=B, max_features=NF)
     g = fe.geometry(NF)
     cap = g.keypoint_capacity
@@ -128,10 +176,12 @@ def main():
                                                  d_match.data_ptr(), d_dist.data_ptr(), d_nm.data_ptr()))
             check(lib.orbgpu_synchronize(fe.handle))
             link_ms = (time.perf_counter() - t1) * 1e3 if it == 0 else min(link_ms, (time.perf_counter() - t1) * 1e3)
+    world_seen = 1
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        world_seen = dist.get_world_size()
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -185,7 +235,7 @@ def main():
     # default workload only, null otherwise
     traffic, traffic_src = None, None
     tfile = ROOT / "profiles" / "r1_hbm_traffic.json"
-    if tfile.exists() and (W, H, NF, B) == (640, 480, 1000, 256):
+    if tfile.exists() and headline:
         tj = json.loads(tfile.read_text())
         traffic = tj["kernels"].get("k_fast_score", {}).get("hbm_bytes")
         traffic_src = "profiles/r1_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this workload)"
@@ -233,12 +283,112 @@ def main():
         bf = min(times[1:])
         peak_measured = fe.popcount_peak()
         nominal = 256 * 64 * 2.4e9 / 16  # CUs x 64 int lanes/clk x 2.4 GHz / 16 lane-ops per pair
+        # 30 % of the 'to' rows are noisy copies (0..40 flipped bits) of 2000 'from' rows: each of those 'from' rows keeps
+        # exactly one claimant, and nothing else comes near TH 50 (the result itself is oracle-checked at this kernel's
+        # sizes in tests/test_gpu_headline.py)
+        n_matched = int((di >= 0).sum().item())
+        assert n_matched == 2000, f"brute-force SNN matched {n_matched} rows, expected 2000"
         matching = {"bruteforce_100k_pairs_per_s": round(n * n / bf, 1), "bruteforce_ms": round(bf * 1e3, 3),
                     "popcount_peak_measured_pairs_per_s": round(peak_measured, 1),
                     "popcount_peak_nominal_pairs_per_s": nominal,
                     "frac_of_measured_peak": round(n * n / bf / peak_measured, 4),
                     "frac_of_nominal_peak": round(n * n / bf / nominal, 4),
-                    "n_matched": int((di >= 0).sum().item())}
+                    "n_matched": n_matched}
+
+    # ---- BASELINE.json configs[2]: large images, extraction throughput vs the HBM roofline (informational) -------
+    large = {}
+    if not args.no_large and world == 1 and headline:
+        for (lw, lh, lb) in ((1920, 1080, 64), (3840, 2160, 32)):
+            lnf = 5000
+            lfe = ORBFeatureExtractor(lw, lh, 1.2, 8, 20, 7, device=local_rank, max_batch=lb, max_features=lnf)
+            lg = lfe.geometry(lnf)
+            lcap, lP = lg.keypoint_capacity, int(lg.pyramid_pixels)
+            lbase = synth.sequence(1236, 4, lh, lw)      # SURVEY 8d input 3; 4 unique frames tiled to the batch
+            lframes = np.ascontiguousarray(lbase[np.arange(lb) % len(lbase)])
+            l_imgs = torch.from_numpy(lframes).to(dev)
+            l_kp = torch.zeros((lb, lcap, 32), dtype=torch.uint8, device=dev)
+            l_desc = torch.zeros((lb, lcap, 32), dtype=torch.uint8, device=dev)
+            l_n = torch.zeros(lb, dtype=torch.int32, device=dev)
+            l_to = torch.arange(1, lb, dtype=torch.int32, device=dev)
+            l_from = torch.arange(0, lb - 1, dtype=torch.int32, device=dev)
+            l_m = torch.zeros((lb - 1, lcap), dtype=torch.int32, device=dev)
+            l_d = torch.zeros((lb - 1, lcap), dtype=torch.int32, device=dev)
+            l_nm = torch.zeros(lb - 1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+
+            def lstep():
+                for rc in (lib.orbgpu_extract_batch_device(lfe.handle, l_imgs.data_ptr(), lw * lh, lw, lb, lnf, l_kp.data_ptr(),
+                                                           l_desc.data_ptr(), lcap, l_n.data_ptr()),
+                           lib.orbgpu_match_frames_device(lfe.handle, l_kp.data_ptr(), l_desc.data_ptr(), l_n.data_ptr(), lcap,
+                                                          l_to.data_ptr(), l_from.data_ptr(), lb - 1, 100, 50, 0.9, 1,
+                                                          l_m.data_ptr(), l_d.data_ptr(), l_nm.data_ptr())):
+                    if rc != 0:
+                        raise RuntimeError(lib.orbgpu_last_error(lfe.handle).decode())
+
+            lstep()
+            torch.cuda.synchronize()
+            lfe.stage_times()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                lstep()
+            torch.cuda.synchronize()
+            l_s = (time.perf_counter() - t1) / 3
+            lst = lfe.stage_times()
+            lA = 5 * lP - lg.w[0] * lg.h[0] - lg.w[lg.levels - 1] * lg.h[lg.levels - 1] + 1978 * lnf
+            large[f"{lw}x{lh}"] = {
+                "frames": lb, "keypoints": lnf, "frames_per_s": round(lb / l_s, 1), "ms_per_batch": round(l_s * 1e3, 3),
+                "extract_ms_per_batch": round(lst["total"], 3),
+                "extract_only_frames_per_s": round(lb / (lst["total"] * 1e-3), 1),
+                "algorithmic_bytes_per_frame": lA,
+                "frac_of_8TBps": round(lA * lb / (lst["total"] * 1e-3) / 1e9 / hbm_peak, 5),
+                "stage_ms": {k: round(float(v), 4) for k, v in lst.items() if k != "total"},
+                "keypoints_mean": round(float(l_n.float().mean().item()), 1),
+                "link_matches_mean": round(float(l_nm.float().mean().item()), 1)}
+            lfe.close()
+            del l_imgs, l_kp, l_desc, l_m, l_d
+            torch.cuda.empty_cache()
+
+    # ---- search by projection (MonocularFrame::SearchInVisiblePoints, monocular_frame.cpp:285-310, radii :358-380) ----
+    # 'to' = the keypoints of frame t-1 standing in for visible map points (descriptor, predicted position = their own
+    # position, predicted level = their level), 'from' = the features of frame t; window = radius multiplier x
+    # scale_factors_[level] truncated to size_t (features.cpp:82), levels [l-1, l+1], TH 100.  One
+    # orbgpu_match_window_device call per frame pair, as the reference makes one MatchWithIterators call per frame.
+    projection = {}
+    if not args.no_projection and n_pairs > 0:
+        from orb_slam3_amd._lib import WindowArgs
+        kp64 = d_kp.view(torch.float64)                          # [B, cap, 4]: x, y, (angle | size), (level | reserved)
+        lvl = d_kp.view(torch.int32)[:, :, 6].contiguous()       # [B, cap]
+        xy = kp64[:, :, :2].contiguous()
+        scale_t = torch.tensor([g.scale[i] for i in range(g.levels)], dtype=torch.float64, device=dev)
+        lmin = torch.clamp(lvl - 1, min=0).contiguous()
+        lmax = (lvl + 1).contiguous()
+        p_idx = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+        p_dist = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+        for mult, ratio in ((15.0, 0.9), (30.0, 0.8)):
+            win = (mult * scale_t[lvl.clamp(0, g.levels - 1).long()]).to(torch.int64).contiguous()   # truncation
+            torch.cuda.synchronize()
+            calls = []
+            for t in range(1, B):
+                a = WindowArgs(d_desc[t - 1].data_ptr(), xy[t - 1].data_ptr(), win[t - 1].data_ptr(), lmin[t - 1].data_ptr(),
+                               lmax[t - 1].data_ptr(), None, int(n_kp[t - 1]), d_desc[t].data_ptr(), xy[t].data_ptr(),
+                               lvl[t].data_ptr(), int(n_kp[t]), 100, ratio)
+                calls.append((a, p_idx[t].data_ptr(), p_dist[t].data_ptr()))
+            best = None
+            for it in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for a, pi, pd in calls:
+                    check(lib.orbgpu_match_window_device(fe.handle, C.byref(a), pi, pd))
+                check(lib.orbgpu_synchronize(fe.handle))
+                dt_ = time.perf_counter() - t1
+                best = dt_ if best is None else min(best, dt_)
+            pairs = float(sum(int(n_kp[t - 1]) * int(n_kp[t]) for t in range(1, B)))
+            nominal = 256 * 64 * 2.4e9 / 16
+            matched = int(sum(int((p_idx[t, :int(n_kp[t - 1])] >= 0).sum().item()) for t in range(1, min(B, 9))))
+            projection[f"radius_{int(mult)}_ratio_{ratio}"] = {
+                "calls": B - 1, "ms": round(best * 1e3, 3), "predicated_pairs": pairs,
+                "predicated_pairs_per_s": round(pairs / best, 1), "frac_of_nominal_popcount_peak": round(pairs / best / nominal, 5),
+                "matches_first_8_pairs": matched}
 
     host_path = {}
     if args.host_path and world == 1:
@@ -333,16 +483,19 @@ def main():
         cpu["frame_parallel"] = {"value": round(n_job / par_s, 2), "unit": "frames/s (extract only)", "cores": n_thr,
                                  "sample": f"{n_job} frames over {n_thr} threads, {par_s:.1f} s"}
 
-    out = {"metric": "frames/sec ORB extract+match (640x480, 8 lvls, 1000 kp); Hamming matches/sec",
+    out = {"metric": f"frames/sec ORB extract+match ({W}x{H}, 8 lvls, {NF} kp); Hamming matches/sec",
            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8", "data": "synthetic",
-           "config": {"workload": f"synthetic {W}x{H} frame batch ({B} frames per GPU), 8 levels, {NF} keypoints, extract + window link match (BASELINE.json configs[1])",
+           "config": {"workload": f"synthetic {W}x{H} frame batch ({B} frames per GPU), 8 levels, {NF} keypoints, extract + window link match"
+                                  + (" (BASELINE.json configs[1])" if headline else " (not the headline configuration)"),
+                      "world_size_observed": world_seen,
                       "frames_per_gpu": B, "keypoints_mean": round(float(n_kp.mean()), 1),
                       "link_matches_mean": round(float(n_matches.mean()), 1) if n_pairs else 0.0,
                       "parallelism": f"frame-sharded x{world}"},
            "roofline": roofline, "pipeline": pipeline, "matching": matching, "keyframe_allpairs": allpairs,
-           "keyframe_database": database, "host_pointer_path": host_path,
+           "keyframe_database": database, "host_pointer_path": host_path, "large_images": large,
+           "projection_match": projection,
            "cpu_baseline": cpu}
     print(json.dumps(out))
     if world > 1:

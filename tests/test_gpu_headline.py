@@ -137,3 +137,27 @@ def test_bruteforce_two_rows_per_lane(oracle, n_to, n_from, settings):
         assert np.array_equal(gd[sel], omd[sel])
         assert sel.sum() > 100
     fe.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2` starts two ranks by itself; ORB_BENCH_REHEARSAL=1 puts both on GPU 0 over gloo (RCCL wants
+    one GPU per rank), so the whole N > 1 flow -- frame sharding, barrier, MAX over ranks, the all-gather of the
+    keyframe shards -- runs on a one-GPU box."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["ORB_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--frames", "8", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-bruteforce", "--no-database"], env=env, capture_output=True, text=True,
+                       timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size_observed"] == 2 and out["value"] > 0
+    assert out["keyframe_allpairs"]["keyframes_total"] == 4 and out["keyframe_allpairs"]["matches_rank0"] > 0
+    assert "not the headline" in out["config"]["workload"]

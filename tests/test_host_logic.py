@@ -170,3 +170,27 @@ def test_keyframe_database_stream_layout():
         db.Append(1, {6: 1.0})
     with pytest.raises(ValueError):
         DBoW2Database(fe, 6).Append(1, {2: 1.0}, {2: 3})       # counts need with_counts=True
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (plain child processes, one per
+    GPU), which rendezvous, reduce their times with MAX and let rank 0 print the line; --dry-run keeps it to that
+    control flow (gloo, no GPU, no compute) so that it runs here."""
+    import json
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size_observed"] == 2 and out["dry_run"] is True
+    # a failing rank fails the launcher: without a GPU every rank of the real bench stops with "needs a GPU"
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--frames", "8"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "rank exit codes" in r.stderr
