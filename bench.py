@@ -394,7 +394,6 @@ def main():
     if args.host_path and world == 1:
         # the boundary the reference's caller uses: host images in, host keypoints / descriptors out (orbgpu_extract_batch),
         # PCIe transfers and host staging included -- informational, never part of `value`
-        import ctypes as C
         ptrs = (C.c_void_p * B)(*[frames[i].ctypes.data for i in range(B)])
         h_kp = np.zeros((B, cap), _lib.KP_DTYPE)
         h_desc = np.zeros((B, cap, 32), np.uint8)
@@ -422,7 +421,6 @@ def main():
         # keyframe BowVectors of 800 words each out of a 100k-word vocabulary; algorithmic bytes = every word id of the
         # database read once (4 B per entry) + the value of every word the query shares (8 B)
         from orb_slam3_amd import _lib as L
-        import ctypes as C
         K, WPK, VOC = 20_000, 800, 100_000
         rng = np.random.default_rng(1239)
         words = np.sort(rng.integers(0, VOC - WPK, (K, WPK), dtype=np.int64), axis=1) + np.arange(WPK)   # strictly ascending rows

@@ -84,11 +84,24 @@ void orbgpu_destroy(orbgpu_ctx *ctx);
 /* message of the last failing call on this context (or of a failed orbgpu_create when ctx == NULL) */
 const char *orbgpu_last_error(const orbgpu_ctx *ctx);
 int orbgpu_get_geometry(const orbgpu_ctx *ctx, int32_t feature_count, orbgpu_geometry *out);
-/* The context enqueues all its work on a stream of its own (a hipStream_t, returned here).  Device buffers that the
- * caller fills or reads on another stream (torch's, say) must be ordered against it: synchronise that stream before a
- * *_device call, and orbgpu_synchronize (or an event on this stream) before reading the results. */
+/* The context enqueues all its work on one stream (a hipStream_t, returned here): a stream of its own unless
+ * orbgpu_set_stream gave it the caller's.  Device buffers that the caller fills or reads on another stream (torch's,
+ * say) must be ordered against it: orbgpu_set_stream / orbgpu_wait_event / orbgpu_record_event below, or a
+ * synchronisation of that stream before a *_device call and orbgpu_synchronize before reading the results. */
 void *orbgpu_stream(orbgpu_ctx *ctx);
 int orbgpu_synchronize(orbgpu_ctx *ctx);
+/* Ordering against the caller's streams without a device-wide synchronisation (no counterpart in the reference, which
+ * never leaves the CPU).  Either
+ *  - orbgpu_set_stream: the context enqueues on the caller's stream (a hipStream_t; NULL = back to its own stream)
+ *    from now on, so the caller's fills, the library's kernels and the caller's reads are ordered by the stream itself
+ *    (work already enqueued on the previous stream is waited for first); or
+ *  - orbgpu_wait_event: the context's stream waits for a hipEvent_t the caller recorded after filling its buffers, and
+ *    orbgpu_record_event: records the caller's hipEvent_t on the context's stream, for the caller's stream to wait on
+ *    before it reads the results.
+ * The stream / event must belong to the context's device and outlive the work that uses it. */
+int orbgpu_set_stream(orbgpu_ctx *ctx, void *stream);
+int orbgpu_wait_event(orbgpu_ctx *ctx, void *event);
+int orbgpu_record_event(orbgpu_ctx *ctx, void *event);
 
 /* ---- extraction ------------------------------------------------------------------------------ */
 /* replaces: IFeatureExtractor::Extract (ifeature_extractor.h:33-35; ORBFeatureExtractor::Extract
@@ -229,7 +242,7 @@ int orbgpu_match_frames_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp, con
  * keypoint a candidate in index order, then ratio / threshold / uniqueness and, when check_orientation != 0,
  * OrientationValidator::Validate (validators/orientation_validator.cpp:16-97).
  * Both sets are laid out like the output of orbgpu_extract_batch_device: keyframe k occupies rows
- * [k*capacity, k*capacity + n[k]) of its descriptor (x32 bytes) and keypoint arrays; capacity <= 4096.
+ * [k*capacity, k*capacity + n[k]) of its descriptor (x32 bytes) and keypoint arrays; capacity <= 4080.
  * row_offset >= 0 names the column index of row 0 when the rows are a slice of the columns (one rank's shard of
  * an all-gathered set): the pair (r, row_offset + r) is then skipped and reports 0 matches; pass -1 otherwise.
  * d_n_matches is n_rows x n_cols; d_match (n_rows x n_cols x capacity, 'from' index or -1) may be NULL.

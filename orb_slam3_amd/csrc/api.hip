@@ -272,6 +272,9 @@ int finish_pipeline(orbgpu_ctx *ctx) {
       *ctx->h_error_flag = 0;
       HIP_TRY(hipMemsetAsync(ctx->d_error_flag, 0, sizeof(int), ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
+      if (code == ORBGPU_ERR_OUT_CAPACITY)
+        return fail(ctx, ORBGPU_E_CAPACITY, "a frame has more keypoints than the caller's capacity: that frame was not written "
+                                            "(its entry of n_out holds the count it needs)");
       return fail(ctx, ORBGPU_E_CAPACITY, "quadtree kernel capacity violation (code " + std::to_string(code) + ")");
     }
   }
@@ -358,7 +361,8 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   auto alloc_all = [&]() -> int {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(match_noalloc_init(ctx->device));  // address of this GPU's copy of the fixed scratch array
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_blur, hipStreamNonBlocking));
     for (auto &set : ctx->ev)
       for (auto &ev : set) HIP_TRY(hipEventCreate(&ev));
@@ -419,7 +423,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
     for (auto &ev : set)
       if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream_blur) (void)hipStreamDestroy(ctx->stream_blur);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
 
@@ -444,6 +448,33 @@ int orbgpu_get_geometry(const orbgpu_ctx *ctx, int32_t feature_count, orbgpu_geo
 }
 
 void *orbgpu_stream(orbgpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int orbgpu_set_stream(orbgpu_ctx *ctx, void *stream) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  // work already enqueued keeps its order: the old stream drains before the switch (this also collects its stage timers
+  // and device-side errors)
+  int rc = finish_pipeline(ctx);
+  ctx->stream = stream ? static_cast<hipStream_t>(stream) : ctx->own_stream;
+  return rc;
+}
+
+int orbgpu_wait_event(orbgpu_ctx *ctx, void *event) {
+  if (!ctx || !event) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamWaitEvent(ctx->stream, static_cast<hipEvent_t>(event), 0));
+  return ORBGPU_OK;
+}
+
+int orbgpu_record_event(orbgpu_ctx *ctx, void *event) {
+  if (!ctx || !event) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), ctx->stream));
+  return ORBGPU_OK;
+}
 
 int orbgpu_synchronize(orbgpu_ctx *ctx) {
   if (!ctx) return ORBGPU_E_INVALID;
@@ -1333,7 +1364,9 @@ int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_ro
   if (!d_desc_rows || !d_n_rows || !d_desc_cols || !d_n_cols || !d_n_matches) return fail(ctx, ORBGPU_E_INVALID, "null argument");
   if (check_orientation && (!d_kp_rows || !d_kp_cols))
     return fail(ctx, ORBGPU_E_INVALID, "check_orientation needs the keypoint arrays of both sets");
-  if (allpairs_lds_bytes(capacity) > 64 * 1024) return fail(ctx, ORBGPU_E_CAPACITY, "capacity above 4096 keypoints per keyframe");
+  // dynamic LDS plus the kernel's static __shared__ (rotation histogram, counters: < 256 B) must fit the 64 KB a
+  // workgroup gets without raising the limit
+  if (allpairs_lds_bytes(capacity) + 256 > 64 * 1024) return fail(ctx, ORBGPU_E_CAPACITY, "capacity above 4080 keypoints per keyframe");
   if ((uint64_t)n_cols * (uint64_t)((n_rows + 7) & ~7) >= (1ull << 31)) return fail(ctx, ORBGPU_E_INVALID, "too many pairs for one call");
   HIP_TRY(hipSetDevice(ctx->device));
   launch_match_allpairs(ctx, d_kp_rows, d_desc_rows, d_n_rows, n_rows, d_kp_cols, d_desc_cols, d_n_cols, n_cols, capacity,

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
                                                               const int *__restrict__ kp_count,
                                                               orbgpu_keypoint *__restrict__ out_kp,
                                                               uint8_t *__restrict__ out_desc, int capacity,
-                                                              int *__restrict__ out_n, int n_frames, Level0Src lvl0) {
+                                                              int *__restrict__ out_n, int n_frames, Level0Src lvl0,
+                                                              int *__restrict__ error_flag) {
   __shared__ unsigned patch[KPG][PATCH_DW];
   __shared__ float s_angle[KPG];
   __shared__ float s_cs[KPG][2];
@@ -217,7 +218,12 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
   }
   __syncthreads();
   const int total = s_prefix[ORBGPU_MAX_LEVELS - 1];
-  if (group == 0 && threadIdx.x == 0) out_n[f] = total;
+  if (group == 0 && threadIdx.x == 0) {
+    out_n[f] = total;
+    // the frame does not fit the caller's arrays: nothing of it is written, the count says how much room it needs, and
+    // the context's error flag makes the next orbgpu_synchronize / orbgpu_stage_times return ORBGPU_E_CAPACITY
+    if (total > capacity) atomicExch(error_flag, ORBGPU_ERR_OUT_CAPACITY);
+  }
   bool any_valid = false;
 #pragma unroll
   for (int h = 0; h < KPW; h++) any_valid |= valid[h];
@@ -273,7 +279,7 @@ void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *
                             int *d_n_out) {
   dim3 grid((c->geom.kps_per_frame + KPG - 1) / KPG * xcd_frames(n_frames));
   hipLaunchKernelGGL(k_orient_describe, grid, dim3(64 * KPB), 0, c->stream, c->d_pyr, c->d_blur, c->geom, c->d_kp_xy,
-                     c->d_kp_count, d_kp, d_desc, capacity, d_n_out, n_frames, c->lvl0);
+                     c->d_kp_count, d_kp, d_desc, capacity, d_n_out, n_frames, c->lvl0, c->d_error_flag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256) void k_keypoint_geometry(orbgpu_camera c, cons
                                                            uint8_t *__restrict__ ok) {
   const int f = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const int count = n ? min(n[f], capacity) : capacity;
+  const int count = n ? usable_count(n[f], capacity) : capacity;
   if (i >= count) return;
   const size_t s = (size_t)f * capacity + i;
   const double fx_inv = c.fx != 0 ? 1 / c.fx : 0, fy_inv = c.fy != 0 ? 1 / c.fy : 1;

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void k_link_partial(const orbgpu_keypoint *__r
                                                       int n_chunks, uint2 *__restrict__ partial) {
   const int p = blockIdx.z;
   const int ft = to_frame[p], ff = from_frame[p];
-  const int n_to = min(n_kp[ft], capacity), n_from = min(n_kp[ff], capacity);
+  const int n_to = usable_count(n_kp[ft], capacity), n_from = usable_count(n_kp[ff], capacity);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x * 256 >= n_to) return;
   const int j0 = blockIdx.y * chunk, j1 = min(j0 + chunk, n_from);
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_link_finalize(const orbgpu_keypoint *__
                                                        unsigned long long *__restrict__ claim) {
   const int p = blockIdx.y;
   const int ft = to_frame[p];
-  const int n_to = min(n_kp[ft], capacity);
+  const int n_to = usable_count(n_kp[ft], capacity);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= capacity) return;
   int j = -1;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void k_link_resolve(const orbgpu_keypoint *__r
                                                       const unsigned *__restrict__ dist, int *__restrict__ n_matches) {
   const int p = blockIdx.x;
   const int ft = to_frame[p], ff = from_frame[p];
-  const int n_to = min(n_kp[ft], capacity);
+  const int n_to = usable_count(n_kp[ft], capacity);
   int *m = match + (size_t)p * capacity;
   const unsigned *dd = dist + (size_t)p * capacity;
   const unsigned long long *cl = claim + (size_t)p * capacity;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void k_link_fused(const orbgpu_keypoint *__res
   __shared__ int total;
   const int p = blockIdx.x;
   const int ft = to_frame[p], ff = from_frame[p];
-  const int n_to = min(n_kp[ft], capacity), n_from = min(n_kp[ff], capacity);
+  const int n_to = usable_count(n_kp[ft], capacity), n_from = usable_count(n_kp[ff], capacity);
   const orbgpu_keypoint *kt = kp + (size_t)ft * capacity, *kf = kp + (size_t)ff * capacity;
   int *m = match + (size_t)p * capacity;
   unsigned *dd = dist + (size_t)p * capacity;
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(256) void k_allpairs(const orbgpu_keypoint *__restr
   if (!xcd_item_frame(n_cols, n_rows, c, r)) return;
   int *out_n = n_matches + (size_t)r * n_cols + c;
   int *out_m = match_out ? match_out + ((size_t)r * n_cols + c) * capacity : nullptr;
-  const int n_to = min(n_rows_kp[r], capacity), n_from = min(n_cols_kp[c], capacity);
+  const int n_to = usable_count(n_rows_kp[r], capacity), n_from = usable_count(n_cols_kp[c], capacity);
   if ((row_offset >= 0 && row_offset + r == c) || n_to == 0 || n_from == 0) {  // a keyframe is not matched with itself
     if (threadIdx.x == 0) *out_n = 0;
     if (out_m)

@@ -81,6 +81,13 @@ __host__ __device__ inline unsigned pack_cand(int x, int y, int s) { return (uns
 
 struct CellEntry { int off, count; };  // segment of a (frame, level) candidate sub-pool
 
+// codes kernels leave in orbgpu_ctx::d_error_flag (1, 3: the quadtree kernel's own capacity checks)
+#define ORBGPU_ERR_OUT_CAPACITY 16  // a frame has more keypoints than the caller's `capacity`: it was not written
+
+// keypoints of a frame that consumers of orbgpu_extract_batch_device's output may read: a frame whose count exceeds the
+// capacity was not written at all (k_orient_describe), so it counts as empty instead of exposing stale rows
+__device__ __forceinline__ int usable_count(int n, int capacity) { return (n < 0 || n > capacity) ? 0 : n; }
+
 #define HIP_TRY(expr)                                                             \
   do {                                                                            \
     hipError_t e_ = (expr);                                                       \
@@ -94,7 +101,8 @@ struct orbgpu_ctx {
   int nini[ORBGPU_MAX_LEVELS]{};
   int rs_pitch[ORBGPU_MAX_LEVELS]{}, rs_rows[ORBGPU_MAX_LEVELS]{};  // LDS footprint of a resize tile (bytes per row, rows)
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // where the context enqueues: its own stream, or the caller's (orbgpu_set_stream)
+  hipStream_t own_stream = nullptr;
   hipStream_t stream_blur = nullptr;  // the blur runs beside the (latency-bound) quadtree kernel
   std::mutex mu;
   std::string err;

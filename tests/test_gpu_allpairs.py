@@ -137,7 +137,11 @@ akp, adesc, an = extract(all_kfs)
 assert all_kfs[off:off + len(kfs)] == kfs
 ref_nm = torch.zeros((len(all_kfs), len(all_kfs)), dtype=torch.int32, device=dev)
 ref_m = torch.zeros((len(all_kfs), len(all_kfs), cap), dtype=torch.int32, device=dev)
-torch.cuda.synchronize()             # or the zero fill can land after the library's writes (it did, once in 25 runs)
+# the zero fills above run on torch's stream, the library on its own: without ordering, a fill can land after the
+# library's writes (it did, once in 25 runs).  An event instead of a device-wide synchronisation:
+ev = torch.cuda.Event()
+ev.record()
+_lib.check(lib.orbgpu_wait_event(fe.handle, ev.cuda_event), fe.handle)
 _lib.check(lib.orbgpu_match_allpairs_device(fe.handle, akp.data_ptr(), adesc.data_ptr(), an.data_ptr(), len(all_kfs),
                                            akp.data_ptr(), adesc.data_ptr(), an.data_ptr(), len(all_kfs), cap, 0, 50, 0.9,
                                            1, ref_nm.data_ptr(), ref_m.data_ptr()), fe.handle)

@@ -268,3 +268,86 @@ def test_concurrent_callers(oracle):
     for fe in [shared] + own:
         fe.close()
     assert not errors, errors
+
+
+def test_caller_stream_and_capacity_flag(oracle):
+    """orbgpu_set_stream: with the context on torch's stream, fills, extraction, linking and torch's reads need no
+    synchronisation at all.  Then the asynchronous capacity error: a frame with more keypoints than `capacity` is not
+    written, orbgpu_synchronize reports ORBGPU_E_CAPACITY, and the link matcher treats that frame as empty."""
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    W, H, NF, B = 320, 240, 400, 4
+    frames = synth.sequence(79, B, H, W)
+    frames[2][:, :] = frames[2][:, :] // 8 * 8                  # frame 2: blocky, fewer corners than the others
+    frames[2][::2] = 90
+    fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_batch=B, max_features=NF)
+    cap = fe.geometry(NF).keypoint_capacity
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        assert lib.orbgpu_set_stream(fe.handle, st.cuda_stream) == 0
+        for rep in range(3):                                        # repeated: a race would need luck to hide three times
+            d_imgs = torch.from_numpy(frames).to(dev, non_blocking=True)
+            d_kp = torch.full((B, cap, 32), 255, dtype=torch.uint8, device=dev)
+            d_desc = torch.full((B, cap, 32), 255, dtype=torch.uint8, device=dev)
+            d_n = torch.full((B,), -7, dtype=torch.int32, device=dev)
+            to = torch.tensor([1, 2, 3], dtype=torch.int32, device=dev)
+            frm = torch.tensor([0, 1, 2], dtype=torch.int32, device=dev)
+            d_m = torch.full((3, cap), 99, dtype=torch.int32, device=dev)
+            d_d = torch.full((3, cap), 99, dtype=torch.int32, device=dev)
+            d_nm = torch.full((3,), 99, dtype=torch.int32, device=dev)
+            rc = lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr(), W * H, W, B, NF, d_kp.data_ptr(),
+                                                 d_desc.data_ptr(), cap, d_n.data_ptr())
+            assert rc == 0, lib.orbgpu_last_error(fe.handle)
+            rc = lib.orbgpu_match_frames_device(fe.handle, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                                                to.data_ptr(), frm.data_ptr(), 3, 100, 50, 0.9, 1, d_m.data_ptr(),
+                                                d_d.data_ptr(), d_nm.data_ptr())
+            assert rc == 0, lib.orbgpu_last_error(fe.handle)
+            n = d_n.cpu().numpy()                                   # torch's own stream-ordered copies
+            desc = d_desc.cpu().numpy()
+            m, nm = d_m.cpu().numpy(), d_nm.cpu().numpy()
+            p = oracle.params(W, H)
+            ok = [oracle.extract(p, frames[f], NF) for f in range(B)]
+            for f in range(B):
+                assert n[f] == len(ok[f][0]) and np.array_equal(desc[f, :n[f]], ok[f][1])
+            for pi in range(3):
+                mf, _ = oracle.match_area(ok[pi + 1][0], ok[pi + 1][1], ok[pi][0], ok[pi][1], 100, 50, 0.9)
+                mf, _ = oracle.orientation_validate(ok[pi + 1][0]["angle"], ok[pi][0]["angle"], mf)
+                assert np.array_equal(m[pi, :n[pi + 1]], mf) and nm[pi] == (mf >= 0).sum()
+        assert lib.orbgpu_synchronize(fe.handle) == 0
+        assert lib.orbgpu_set_stream(fe.handle, None) == 0          # back on the context's own stream
+    torch.cuda.synchronize()
+    # ---- capacity smaller than some frames need ----------------------------------------------------------
+    small = int(np.sort(n)[1])                                      # at least two frames do not fit, at least one does
+    assert n.min() <= small < n.max()
+    d_kp = torch.full((B, small, 32), 255, dtype=torch.uint8, device=dev)
+    d_desc = torch.full((B, small, 32), 255, dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_m = torch.full((3, small), 99, dtype=torch.int32, device=dev)
+    d_d = torch.full((3, small), 99, dtype=torch.int32, device=dev)
+    d_nm = torch.full((3,), 99, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    rc = lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr(), W * H, W, B, NF, d_kp.data_ptr(),
+                                         d_desc.data_ptr(), small, d_n.data_ptr())
+    assert rc == 0                                                  # asynchronous: the violation is found on the device
+    rc = lib.orbgpu_match_frames_device(fe.handle, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), small,
+                                        to.data_ptr(), frm.data_ptr(), 3, 100, 50, 0.9, 1, d_m.data_ptr(), d_d.data_ptr(),
+                                        d_nm.data_ptr())
+    assert rc == 0
+    assert lib.orbgpu_synchronize(fe.handle) == _lib.E_CAPACITY
+    assert b"capacity" in lib.orbgpu_last_error(fe.handle)
+    assert lib.orbgpu_synchronize(fe.handle) == 0                  # reported once, then cleared
+    n2 = d_n.cpu().numpy()
+    assert np.array_equal(n2, n)                                    # the counts say what each frame needs
+    desc2, m2, nm2 = d_desc.cpu().numpy(), d_m.cpu().numpy(), d_nm.cpu().numpy()
+    for f in range(B):
+        if n[f] <= small:
+            assert np.array_equal(desc2[f, :n[f]], ok[f][1])
+        else:
+            assert (desc2[f] == 255).all()                          # not written
+    for pi in range(3):
+        if n[pi] > small or n[pi + 1] > small:
+            assert nm2[pi] == 0 and (m2[pi] == -1).all()            # an overflowed frame counts as empty
+    fe.close()
