@@ -224,9 +224,14 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   HIP_TRY(hipEventRecord(ev[0], ctx->stream));
   for (int l = 1; l < L; l++) launch_pyramid_level(ctx, n_frames, l);
   HIP_TRY(hipEventRecord(ev[1], ctx->stream));
-  launch_fast_score(ctx, n_frames);
-  HIP_TRY(hipEventRecord(ev[2], ctx->stream));
-  launch_cell_detect(ctx, n_frames);
+  if (ctx->old_fast) {
+    launch_fast_score(ctx, n_frames);
+    HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+    launch_cell_detect(ctx, n_frames);
+  } else {
+    launch_fast_cells(ctx, n_frames, nullptr);
+    HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+  }
   HIP_TRY(hipEventRecord(ev[3], ctx->stream));
   // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
   // dependent rounds in 8 x n_frames workgroups and leaves most of the chip idle
@@ -330,6 +335,8 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   {
     const char *z = std::getenv("ORBGPU_NO_ZERO_COPY");
     ctx->no_zero_copy = z && z[0] == '1';
+    const char *o = std::getenv("ORBGPU_OLD_FAST");
+    ctx->old_fast = o && o[0] == '1';
   }
   auto bail = [&](int rc) {
     g_create_error = ctx->err;
@@ -378,6 +385,13 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(dmalloc(&ctx->d_ytab, yt.size()));
     HIP_TRY(hipMemcpyAsync(ctx->d_xtab, xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_ytab, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice, ctx->stream));
+    {
+      std::vector<short> groups;
+      ctx->n_fast_groups = build_fast_groups(g, groups);
+      for (int l = 0; l < g.levels; l++) ctx->fast_lds_rows = std::max(ctx->fast_lds_rows, g.lv[l].hcell);
+      HIP_TRY(dmalloc(&ctx->d_fast_groups, groups.size()));
+      HIP_TRY(hipMemcpy(ctx->d_fast_groups, groups.data(), groups.size() * sizeof(short), hipMemcpyHostToDevice));
+    }
     HIP_TRY(dmalloc(&ctx->d_cells, B * g.cells_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cands, B * g.cands_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cands_packed, B * g.cands_per_frame));
@@ -413,7 +427,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   void *dptrs[] = {ctx->d_nzmask, ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes,
-                   ctx->d_error_flag};
+                   ctx->d_error_flag, ctx->d_fast_groups};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
   void *hptrs[] = {ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};
@@ -621,6 +635,14 @@ int orbgpu_debug_dump(orbgpu_ctx *ctx, int32_t frame, uint8_t *pyramid, uint8_t 
   const DeviceGeom &g = ctx->geom;
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (score && !ctx->old_fast) {
+    // the product path keeps no score map: re-run the fused kernel on the (still resident) pyramid of the last call with
+    // its DUMP switch, which scatters every non-zero score into d_score
+    HIP_TRY(hipMemsetAsync(ctx->d_score, 0, (size_t)ctx->last_frames * g.frame_bytes, ctx->stream));
+    launch_fast_cells(ctx, ctx->last_frames, ctx->d_score);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
   std::vector<uint8_t> slab(g.frame_bytes);
   const uint8_t *srcs[3] = {ctx->d_pyr, ctx->d_score, ctx->d_blur};
   uint8_t *dsts[3] = {pyramid, score, blurred};

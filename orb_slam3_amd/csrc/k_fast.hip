@@ -5,7 +5,9 @@
 // (cv::FAST :259-266).  Closed form used:
 //   d_k = v - ring_k,  M_dark = max over the 16 arcs of min over 9 contiguous d,
 //   M_bright = max over arcs of min(-d),  score = max(M_dark, M_bright) - 1,  corner at t  <=>  score >= t.
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "orbgpu_internal.h"
 #include "tile_stage.hpp"
@@ -434,11 +436,333 @@ __global__ __launch_bounds__(64 * CELLS_PER_WG) void k_cell_detect(const uint8_t
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused FAST score + per-cell NMS + threshold fallback + compaction on CELL-ALIGNED tiles.
+//
+// cv::FAST runs per cell in the reference (orb_feature_extractor.cpp:244-266), so its 3x3 non-maximum suppression is
+// blind across cell seams and a workgroup that owns whole cells needs nothing from its neighbours.
+// A workgroup takes one "group": up to 4 horizontally adjacent cells of one cell row (<= 128 pixels wide, <= 64 rows),
+// stages the pixels of their detection rectangles plus the 3-pixel ring apron, and keeps every intermediate in LDS:
+//   phase 1  quick test on pixel PAIRS in packed u16 (4 opposite ring pairs), 4 pixels x 1 row per lane and pass, the
+//            group's quads (4-pixel columns x rows) dealt out flat so that no lane idles whatever the cell geometry;
+//            candidate flags come from saturating packed arithmetic, no compares;
+//   push     survivors -> LDS queue, one LDS atomic per wave;
+//   phase 2  full 9-arc score per survivor -> score tile in LDS (zero apron);
+//   phase 3  3x3 NMS per scored pixel, neighbours outside the pixel's own cell masked; survivors set a bit in their
+//            cell's row mask, one mask for "kept" and one for "kept and >= iniThFAST";
+//   phase 4  one wave per cell: threshold fallback decided after NMS, survivors written in raster order to the cell's
+//            fixed slot of the candidate pool, CellEntry written.
+// No score map, no bit plane and no second kernel: the only global traffic is the tile read and the candidates.
+// DUMP = true additionally scatters the non-zero scores into a global score map (orbgpu_debug_dump's stage test).
+struct FastGroup { short level, row, j0, ncell; };  // cells j0 .. j0 + ncell - 1 of cell row `row`
+
+constexpr int FC_TP = 36;               // dwords per staged / score row (<= 33 quads + 2 apron dwords)
+constexpr int FC_TPB = FC_TP * 4;
+constexpr int FC_MAXK = 4;              // cells per group
+constexpr int FC_QPITCH = 136;          // queue entries per row (<= 33 quads x 4 pixels)
+constexpr int FC_MAXROWS = 64;          // rows of a cell (hcell <= 64 is checked at create time)
+
+__host__ __device__ constexpr size_t fast_cells_lds_bytes(int rows) {
+  return (size_t)(rows + 6) * FC_TPB       // pixel tile
+         + (size_t)(rows + 2) * FC_TPB     // score tile
+         + (size_t)rows * FC_QPITCH * 2    // survivor queue (u16)
+         + (size_t)rows * FC_MAXK * 16     // row masks per (row, cell): kept (u64), kept-hi (u64)
+         + FC_TP * 4                       // column validity mask per quad
+         + 16;
+}
+
+__device__ __forceinline__ int div_small(int q, int d, float inv_d) {
+  // q / d for 0 <= q < 2^20, 1 <= d: estimate + two-sided fix-up
+  int r = (int)((float)q * inv_d);
+  const int rem = q - r * d;
+  if (rem < 0) r--;
+  if (rem >= d) r++;
+  return r;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave: four row_shr steps inside each 16-lane row, then the row totals
+// travel with row_bcast:15 / row_bcast:31 (lanes without a source add 0)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
+template <bool DUMP>
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, DeviceGeom g,
+                                                    const FastGroup *__restrict__ groups, int groups_per_frame,
+                                                    CellEntry *__restrict__ cells, unsigned *__restrict__ cands,
+                                                    int n_frames, Level0Src lvl0, int lds_rows,
+                                                    uint8_t *__restrict__ score_dump) {
+  extern __shared__ __attribute__((aligned(16))) unsigned fc_lds[];
+  unsigned *tile = fc_lds;
+  unsigned *stile = tile + (lds_rows + 6) * FC_TP;
+  unsigned short *queue = reinterpret_cast<unsigned short *>(stile + (lds_rows + 2) * FC_TP);
+  unsigned *rmask = reinterpret_cast<unsigned *>(queue + lds_rows * FC_QPITCH);  // [row][cell]{lo.x, lo.y, hi.x, hi.y}
+  unsigned *colmask = rmask + lds_rows * FC_MAXK * 4;
+  int *q_count = reinterpret_cast<int *>(colmask + FC_TP);
+  int item, frame;
+  if (!xcd_item_frame(groups_per_frame, n_frames, item, frame)) return;
+  const FastGroup G = groups[item];
+  const int l = G.level;
+  const LevelGeom L = g.lv[l];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // detection rectangle of the group: rows of cell row G.row, columns of cells j0 .. j0 + ncell - 1
+  const int Y0 = ORB_EDGE + G.row * L.hcell, Y1 = min(ORB_EDGE - 1 + (G.row + 1) * L.hcell, L.h - ORB_EDGE - 1);
+  const int X0 = ORB_EDGE + G.j0 * L.wcell, X1 = min(ORB_EDGE - 1 + (G.j0 + G.ncell) * L.wcell, L.w - ORB_EDGE - 1);
+  const int nrow = Y1 - Y0 + 1, ncolpx = X1 - X0 + 1;
+  const int cell_slot = ((L.wcell + 1) >> 1) * ((L.hcell + 1) >> 1);
+  CellEntry *ce = cells + (size_t)frame * g.cells_per_frame + L.cell_off + G.row * L.ncols + G.j0;
+  if (nrow <= 0 || ncolpx <= 0) {  // nothing to detect in any cell of the group
+    if (tid < G.ncell) ce[tid] = CellEntry{0, 0};
+    return;
+  }
+  const int xs0 = X0 & ~3;                         // first quad column; tile byte column c <-> level x = xs0 - 4 + c
+  const int ncg = ((X1 - xs0) >> 2) + 1;           // quads per row, <= 33
+  const int ndw = ncg + 2;                         // staged dwords per row
+  const int nq4 = ncg * nrow;
+  const uint8_t *src = level_src(pyr, g, lvl0, frame, l, L.off) + (size_t)(Y0 - 3) * L.pitch + (xs0 - 4);
+
+  // ---- stage (nrow + 6) x ndw dwords: wave = row (w, w + 4, ...), lane = dword; every address is inside the image
+  //      (Y0 >= 19, Y1 <= h - 20, X1 <= w - 20).  All loads of a wave are issued before its first LDS write ----
+  {
+    constexpr int NR = (FC_MAXROWS + 6 + 3) / 4;
+    const int nst = nrow + 6;
+    unsigned v[NR];
+    const uint8_t *lsrc = src + 4 * lane;
+    const bool on = lane < ndw;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const int r = wave + 4 * k;  // wave-uniform
+      v[k] = 0;
+      if (r < nst && on) v[k] = *reinterpret_cast<const unsigned *>(lsrc + (size_t)r * L.pitch);
+    }
+    // meanwhile: clear the score tile and the row masks (16 bytes per lane and store), per-quad column masks
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (nrow + 2) * (FC_TP / 4); i += 256) reinterpret_cast<uint4 *>(stile)[i] = z4;
+    if (tid < nrow * FC_MAXK) reinterpret_cast<uint4 *>(rmask)[tid] = z4;
+    if (tid == 0) *q_count = 0;
+    if (tid < FC_TP) {
+      unsigned m = 0;
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const int x = xs0 + 4 * tid + p;
+        if (x >= X0 && x <= X1) m |= 1u << (8 * p);
+      }
+      colmask[tid] = m;
+    }
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const int r = wave + 4 * k;
+      if (r < nst && on) tile[r * FC_TP + lane] = v[k];
+    }
+  }
+  __syncthreads();
+
+  const int t_lo = g.fast_min, t_hi = g.fast_init;
+  const float inv_ncg = 1.0f / (float)ncg;
+  // candidate <=> max(v - max_k min(pair_k), min_k max(pair_k) - v) > t: with saturating u16 arithmetic the sum
+  // max(...) + (255 - t) has bit 8 set exactly then
+  const unsigned short bias = (unsigned short)(255 - t_lo);
+  const u16x2 bias2 = {bias, bias};
+  // the lane's quad of pass k is q = tid + 256 k = (row ry, quad column cq), advanced by (d_r, d_c) per pass
+  int ry = div_small(tid, ncg, inv_ncg), cq = tid - ry * ncg;
+  const int d_r = __builtin_amdgcn_readfirstlane(div_small(256, ncg, inv_ncg)), d_c = 256 - d_r * ncg;
+  // ---- phase 1 + push, 8 passes (2048 quads) at a time ------------------------------------------------------
+  for (int qbase = 0; qbase < nq4; qbase += 2048) {
+    unsigned acc = 0;  // bit 8 * p + pass: pixel p of this lane's quad in pass `pass` may be a corner
+    const int npass = min(8, (nq4 - qbase + 255) >> 8);
+#pragma unroll 1
+    for (int pass = 0; pass < npass; pass++) {
+      if (qbase + 256 * pass + tid < nq4) {
+        const unsigned *tw = tile + ry * FC_TP + cq;
+        // 12-byte windows (columns x-4 .. x+7) of the 7 rows y-3 .. y+3; x = xs0 + 4 cq
+        unsigned w[7][3];
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) w[j][c] = tw[j * FC_TP + c];
+        unsigned hi_bytes[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+          u16x2 r[16];
+          // ring (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3);
+          // only the even positions are used by the quick test
+          if (pr == 0) {
+            r[0] = pair_bytes<4>(w[6]);  r[2] = pair_bytes<6>(w[5]);  r[4] = pair_bytes<7>(w[3]);  r[6] = pair_bytes<6>(w[1]);
+            r[8] = pair_bytes<4>(w[0]);  r[10] = pair_bytes<2>(w[1]); r[12] = pair_bytes<1>(w[3]); r[14] = pair_bytes<2>(w[5]);
+          } else {
+            r[0] = pair_bytes<6>(w[6]);  r[2] = pair_bytes<8>(w[5]);  r[4] = pair_bytes<9>(w[3]);  r[6] = pair_bytes<8>(w[1]);
+            r[8] = pair_bytes<6>(w[0]);  r[10] = pair_bytes<4>(w[1]); r[12] = pair_bytes<3>(w[3]); r[14] = pair_bytes<4>(w[5]);
+          }
+          const u16x2 v = pr == 0 ? pair_bytes<4>(w[3]) : pair_bytes<6>(w[3]);
+          u16x2 mx_of_min = __builtin_elementwise_min(r[0], r[8]);
+          u16x2 mn_of_max = __builtin_elementwise_max(r[0], r[8]);
+#pragma unroll
+          for (int k = 2; k < 8; k += 2) {
+            mx_of_min = __builtin_elementwise_max(mx_of_min, __builtin_elementwise_min(r[k], r[k + 8]));
+            mn_of_max = __builtin_elementwise_min(mn_of_max, __builtin_elementwise_max(r[k], r[k + 8]));
+          }
+          const u16x2 dk = __builtin_elementwise_sub_sat(v, mx_of_min);   // how far below the centre a dark arc can sit
+          const u16x2 br = __builtin_elementwise_sub_sat(mn_of_max, v);   // how far above a bright one
+          hi_bytes[pr] = as_u32(__builtin_elementwise_max(dk, br) + bias2);
+        }
+        // bytes 1 and 3 of both results: 0 or 1 per pixel, pixel p in byte p
+        const unsigned flags = __builtin_amdgcn_perm(hi_bytes[1], hi_bytes[0], 0x07050301u) & colmask[cq];
+        acc |= flags << pass;
+      }
+      cq += d_c;
+      ry += d_r;
+      if (cq >= ncg) {
+        cq -= ncg;
+        ry++;
+      }
+    }
+    // ---- push the survivors as (quad << 2 | pixel): one LDS atomic per wave; the order inside the queue is free ----
+    {
+      const int cnt = __popc(acc);  // 0..32
+      const int incl = wave_incl_scan(cnt);
+      const int tot = __builtin_amdgcn_readlane(incl, 63);
+      if (tot) {
+        int basep = 0;
+        if (lane == 0) basep = atomicAdd(q_count, tot);
+        int pos = __builtin_amdgcn_readfirstlane(basep) + incl - cnt;
+        const unsigned qt = (unsigned)(qbase + tid) << 2;
+        unsigned m = acc;
+        while (m) {
+          const int bit = __ffs(m) - 1;
+          m &= m - 1;
+          queue[pos++] = (unsigned short)(qt + ((unsigned)(bit & 7) << 10) + ((unsigned)bit >> 3));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: full score of the survivors -> score tile; the queue entry becomes (row << 8 | column) ------------
+  const int nq = *q_count;
+  const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
+  uint8_t *sb = reinterpret_cast<uint8_t *>(stile);
+  for (int q = tid; q < nq; q += 256) {
+    const int e = queue[q];
+    const int ey = div_small(e >> 2, ncg, inv_ncg), cx = 4 * ((e >> 2) - ey * ncg) + (e & 3);
+    const uint8_t *c = tb + (ey + 3) * FC_TPB + cx + 4;
+    constexpr int RP = FC_TPB;
+    int r[16];
+    r[0] = c[3 * RP];       r[1] = c[3 * RP + 1];   r[2] = c[2 * RP + 2];   r[3] = c[RP + 3];
+    r[4] = c[3];            r[5] = c[-RP + 3];      r[6] = c[-2 * RP + 2];  r[7] = c[-3 * RP + 1];
+    r[8] = c[-3 * RP];      r[9] = c[-3 * RP - 1];  r[10] = c[-2 * RP - 2]; r[11] = c[-RP - 3];
+    r[12] = c[-3];          r[13] = c[RP - 3];      r[14] = c[2 * RP - 2];  r[15] = c[3 * RP - 1];
+    const int sc = fast_score16_full((int)c[0], r, t_lo);
+    queue[q] = (unsigned short)((ey << 8) | cx);
+    if (sc) {
+      sb[(ey + 1) * FC_TPB + cx + 4] = (uint8_t)sc;
+      if (DUMP) score_dump[(size_t)frame * g.frame_bytes + L.off + (size_t)(Y0 + ey) * L.pitch + (xs0 + cx)] = (uint8_t)sc;
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: 3x3 NMS inside the pixel's own cell; one sweep serves both thresholds ------------------------------
+  const int bnd0 = X0 - xs0;  // tile column - 4 of the first pixel of cell j0
+  for (int q = tid; q < nq; q += 256) {
+    const int e = queue[q];
+    const int ey = e >> 8, cx = e & 255;
+    const uint8_t *c = sb + (ey + 1) * FC_TPB + cx + 4;
+    const int v = c[0];
+    if (v == 0) continue;
+    const int rel = cx - bnd0;
+    const int j = (rel >= L.wcell) + (rel >= 2 * L.wcell) + (rel >= 3 * L.wcell);
+    const int xx = rel - j * L.wcell;  // column inside the cell
+    int nl = vmax3(c[-FC_TPB - 1], c[-1], c[FC_TPB - 1]);
+    int nr = vmax3(c[-FC_TPB + 1], c[1], c[FC_TPB + 1]);
+    nl = xx == 0 ? 0 : nl;                  // "NMS does not see across the seam"
+    nr = xx == L.wcell - 1 ? 0 : nr;        // (beyond X1 nothing was scored)
+    const int nm = vmax3(c[-FC_TPB], c[FC_TPB], max(nl, nr));
+    if (v > nm) {                           // the score tile holds 0 below fast_min
+      unsigned *mrow = rmask + ((ey * FC_MAXK + j) << 2) + (xx >> 5);
+      atomicOr(mrow, 1u << (xx & 31));
+      if (v >= t_hi) atomicOr(mrow + 2, 1u << (xx & 31));
+    }
+  }
+  __syncthreads();
+  // ---- phase 4: wave = cell, lane = row; fallback decided per cell AFTER NMS (orb_feature_extractor.cpp:263-266) ----
+  if (wave >= G.ncell) return;
+  {
+    const int j = wave;
+    const int cx0 = X0 + j * L.wcell, cx1 = min(cx0 + L.wcell - 1, X1);
+    const int ci = G.row * L.ncols + G.j0 + j;
+    if (cx1 < cx0) {
+      if (lane == 0) ce[j] = CellEntry{0, 0};
+      return;
+    }
+    uint4 mk = make_uint4(0, 0, 0, 0);
+    if (lane < nrow) mk = reinterpret_cast<const uint4 *>(rmask)[lane * FC_MAXK + j];
+    const int c_lo = __popc(mk.x) + __popc(mk.y), c_hi = __popc(mk.z) + __popc(mk.w);
+    const int cnt2 = (c_hi << 16) | c_lo;  // both scans at once (a cell holds < 2^12 survivors)
+    const int incl = wave_incl_scan(cnt2);
+    const int tot = __builtin_amdgcn_readlane(incl, 63);
+    const bool use_hi = (tot >> 16) > 0;
+    const int total = use_hi ? (tot >> 16) : (tot & 0xffff);
+    // every cell owns a fixed slot of ceil(wCell/2) * ceil(hCell/2) entries in its level's sub-pool: NMS survivors
+    // are never adjacent, so the slot cannot overflow and no atomic is needed
+    const int basei = ci * cell_slot;
+    if (lane == 0) ce[j] = CellEntry{basei, total};
+    if (total == 0) return;
+    unsigned long long bits = use_hi ? (((unsigned long long)mk.w << 32) | mk.z) : (((unsigned long long)mk.y << 32) | mk.x);
+    int pos = use_hi ? ((incl - cnt2) >> 16) : ((incl - cnt2) & 0xffff);
+    unsigned *out = cands + (size_t)frame * g.cands_per_frame + L.cand_off + basei;
+    const uint8_t *srow = sb + (lane + 1) * FC_TPB + 4 + (cx0 - xs0);
+    const unsigned ybits = (unsigned)(Y0 + lane - ORB_MIN_BORDER) << 12;
+    while (bits) {
+      const int xx = __ffsll((long long)bits) - 1;
+      bits &= bits - 1;
+      out[pos++] = (unsigned)(cx0 + xx - ORB_MIN_BORDER) | ybits | ((unsigned)srow[xx] << 24);
+    }
+  }
+}
+
 }  // namespace
 
 void launch_fast_score(const orbgpu_ctx *c, int n_frames) {
   dim3 grid(c->geom.ftiles_per_frame * xcd_frames(n_frames));
   hipLaunchKernelGGL(k_fast_score, grid, dim3(256), 0, c->stream, c->d_pyr, c->d_score, c->d_nzmask, c->geom, n_frames, c->lvl0);
+}
+
+size_t fast_cells_lds(int rows) { return fast_cells_lds_bytes(rows); }
+
+// groups of up to FC_MAXK cells, <= 128 pixels wide, balanced over a cell row; host side of k_fast_cells
+int build_fast_groups(const DeviceGeom &g, std::vector<short> &table) {
+  table.clear();
+  for (int l = 0; l < g.levels; l++) {
+    const LevelGeom &L = g.lv[l];
+    const int kmax = std::max(1, std::min(FC_MAXK, 128 / L.wcell));
+    const int gcols = (L.ncols + kmax - 1) / kmax;
+    for (int i = 0; i < L.nrows; i++)
+      for (int q = 0; q < gcols; q++) {
+        const int j0 = q * L.ncols / gcols, j1 = (q + 1) * L.ncols / gcols;
+        table.push_back((short)l);
+        table.push_back((short)i);
+        table.push_back((short)j0);
+        table.push_back((short)(j1 - j0));
+      }
+  }
+  return (int)(table.size() / 4);
+}
+
+void launch_fast_cells(const orbgpu_ctx *c, int n_frames, uint8_t *score_dump) {
+  dim3 grid(c->n_fast_groups * xcd_frames(n_frames));
+  const FastGroup *groups = reinterpret_cast<const FastGroup *>(c->d_fast_groups);
+  const size_t lds = fast_cells_lds_bytes(c->fast_lds_rows);
+  if (score_dump)
+    hipLaunchKernelGGL(k_fast_cells<true>, grid, dim3(256), lds, c->stream, c->d_pyr, c->geom, groups, c->n_fast_groups,
+                       c->d_cells, c->d_cands, n_frames, c->lvl0, c->fast_lds_rows, score_dump);
+  else
+    hipLaunchKernelGGL(k_fast_cells<false>, grid, dim3(256), lds, c->stream, c->d_pyr, c->geom, groups, c->n_fast_groups,
+                       c->d_cells, c->d_cands, n_frames, c->lvl0, c->fast_lds_rows, (uint8_t *)nullptr);
 }
 
 void launch_cell_detect(const orbgpu_ctx *c, int n_frames) {

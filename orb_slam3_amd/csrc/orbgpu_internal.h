@@ -113,6 +113,10 @@ struct orbgpu_ctx {
   mutable size_t qt_lds_configured[2] = {0, 0};  // dynamic-LDS limit already raised for k_quadtree<256> / <1024>
   bool no_zero_copy = false;      // ORBGPU_NO_ZERO_COPY=1: always copy level 0 into the slab (cross-check path)
   unsigned *d_nzmask = nullptr;   // [frame][mask_dwords_per_frame]: bit x of row y set iff score(x, y) != 0
+  short *d_fast_groups = nullptr; // FastGroup table of k_fast_cells (level, cell row, first cell, cells), one frame's worth
+  int n_fast_groups = 0;
+  int fast_lds_rows = 0;          // tallest cell of any level: sizes the dynamic LDS of k_fast_cells
+  bool old_fast = false;          // ORBGPU_OLD_FAST=1: score map + k_cell_detect (A/B measurements)
   XTab *d_xtab = nullptr;
   YTab *d_ytab = nullptr;
   CellEntry *d_cells = nullptr;   // [frame][cells_per_frame]
@@ -165,6 +169,9 @@ int fail_hip(orbgpu_ctx *ctx, hipError_t e, const char *expr, const char *file, 
 void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level);
 void launch_fast_score(const orbgpu_ctx *c, int n_frames);
 void launch_cell_detect(const orbgpu_ctx *c, int n_frames);
+// fused FAST score + cell NMS (k_fast.hip); score_dump != nullptr: also scatter the non-zero scores into that slab
+int build_fast_groups(const DeviceGeom &g, std::vector<short> &table);
+void launch_fast_cells(const orbgpu_ctx *c, int n_frames, uint8_t *score_dump);
 void launch_blur(const orbgpu_ctx *c, int n_frames, hipStream_t stream);
 void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                             int *d_n_out);
