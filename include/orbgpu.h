@@ -100,6 +100,10 @@ int orbgpu_synchronize(orbgpu_ctx *ctx);
  *    before it reads the results.
  * The stream / event must belong to the context's device and outlive the work that uses it. */
 int orbgpu_set_stream(orbgpu_ctx *ctx, void *stream);
+/* A batch is extracted in slices of frames that run side by side on streams forked from (and joined back into) the
+ * context's stream.  n_slices = 0 (the default) lets the library choose (2 from 64 frames on, else 1); 1 .. 4 force
+ * it -- 1 is what a per-kernel profile wants, since the stage timers then see one kernel at a time. */
+int orbgpu_set_batch_slices(orbgpu_ctx *ctx, int32_t n_slices);
 int orbgpu_wait_event(orbgpu_ctx *ctx, void *event);
 int orbgpu_record_event(orbgpu_ctx *ctx, void *event);
 
@@ -375,8 +379,10 @@ int orbgpu_bowdb_query(orbgpu_bowdb *db, const uint32_t *q_words, const double *
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-stage GPU time in milliseconds (HIP events on the context's stream), averaged over the extract calls
  * enqueued since the last orbgpu_synchronize / orbgpu_stage_times (at most the last 32); waits for the stream.
- * [0] pyramid [1] fast score [2] cell NMS + compaction [3] quadtree [4] blur [5] orientation + descriptor
- * [6] total.  Used by bench.py for the roofline line. */
+ * [0] pyramid [1] FAST score + cell NMS / fallback / compaction (one fused kernel) [2] 0 (that stage has no kernel of its
+ * own any more) [3] quadtree [4] blur [5] orientation + descriptor [6] total.  With more than one slice per batch
+ * (orbgpu_set_batch_slices) [0]..[5] are the kernels of slice 0 -- its share of the frames, running beside the other
+ * slices -- and [6] still spans the whole batch.  Used by bench.py for the roofline line. */
 int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms7);
 /* Runs a register-resident XOR + v_bcnt_u32_b32 loop and returns descriptor pairs per second: the
  * measured popcount ceiling that BASELINE.md asks to report next to the nominal one. */

@@ -65,7 +65,7 @@ assert KP_DTYPE.itemsize == 32
 
 # every symbol include/orbgpu.h declares (the inline orbgpu_hamming256 aside)
 EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_geometry", "orbgpu_stream",
-           "orbgpu_synchronize", "orbgpu_set_stream", "orbgpu_wait_event", "orbgpu_record_event", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
+           "orbgpu_synchronize", "orbgpu_set_stream", "orbgpu_set_batch_slices", "orbgpu_wait_event", "orbgpu_record_event", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
            "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_bruteforce_noalloc_device",
            "orbgpu_match_window",
            "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
@@ -98,6 +98,7 @@ def load():
         "orbgpu_stream": (vp, [vp]),
         "orbgpu_synchronize": (i32, [vp]),
         "orbgpu_set_stream": (i32, [vp, vp]),
+        "orbgpu_set_batch_slices": (i32, [vp, i32]),
         "orbgpu_wait_event": (i32, [vp, vp]),
         "orbgpu_record_event": (i32, [vp, vp]),
         "orbgpu_extract": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]),

@@ -64,7 +64,7 @@ int build_geometry(orbgpu_ctx *ctx) {
   int budget[ORBGPU_MAX_LEVELS];
   level_budget(p.scale_factor, p.levels, p.max_features, budget);
   unsigned off = 0;
-  int cell_off = 0, cand_off = 0, kp_off = 0, ftile_off = 0, btile_off = 0, xt = 0, yt = 0, mask_off = 0;
+  int cell_off = 0, cand_off = 0, kp_off = 0, btile_off = 0, xt = 0, yt = 0;
   for (int l = 0; l < p.levels; l++) {
     LevelGeom &L = g.lv[l];
     const float s = (float)ctx->inv_scale[l];  // :506-508
@@ -93,11 +93,6 @@ int build_geometry(orbgpu_ctx *ctx) {
     L.kp_off = kp_off;
     L.kp_cap = std::max(budget[l], 0) + 4 * ctx->nini[l] + 4;  // the node list overshoots the budget by < 3
     kp_off += L.kp_cap;
-    L.ftile_off = ftile_off;
-    L.mask_pitch = ((L.w + 127) / 128) * 4;  // whole 128-pixel tiles: the FAST kernel writes 4 dwords per tile row
-    L.mask_off = mask_off;
-    mask_off += L.mask_pitch * L.h;
-    ftile_off += ((L.w + 127) / 128) * ((L.h + 31) / 32);
     L.btile_off = btile_off;
     btile_off += ((L.w + 127) / 128) * ((L.h + ORBGPU_BLUR_TILE_H - 1) / ORBGPU_BLUR_TILE_H);
     L.xtab_off = xt;
@@ -111,14 +106,11 @@ int build_geometry(orbgpu_ctx *ctx) {
   g.cells_per_frame = cell_off;
   g.cands_per_frame = cand_off;
   g.kps_per_frame = kp_off;
-  g.ftiles_per_frame = ftile_off;
   g.btiles_per_frame = btile_off;
   for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) {
     g.kp_offs[l] = l < g.levels ? g.lv[l].kp_off : INT_MAX;
-    g.ftile_offs[l] = l < g.levels ? g.lv[l].ftile_off : INT_MAX;
     g.cell_offs[l] = l < g.levels ? g.lv[l].cell_off : INT_MAX;
   }
-  g.mask_dwords_per_frame = mask_off;
   return 0;
 }
 
@@ -211,8 +203,13 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 }
 
 // The whole extraction pipeline on device-resident level-0 images already imported into ctx->d_pyr.
-// Everything is enqueued on the context's stream; nothing here waits for the GPU.  Stage times and the device
+// Everything is enqueued on the context's streams; nothing here waits for the GPU.  Stage times and the device
 // error flag are collected by finish_pipeline().
+//
+// The batch is cut into slices of frames that run side by side, slice 0 on the context's stream and the others on
+// streams forked from it (and joined back into it at the end): every kernel here is bound by instruction issue or by
+// latency, never by HBM, so the dependent, latency-bound stages of one slice (quadtree rounds, orientation ->
+// descriptor chains, small pyramid levels) fill issue slots that the instruction-bound stages of another leave.
 int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                  int *d_n_out) {
   const DeviceGeom &g = ctx->geom;
@@ -221,38 +218,52 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   level_budget(ctx->params.scale_factor, L, feature_count, budget);
   // the device error flag is sticky: it is only cleared by finish_pipeline(), so queued calls cannot hide an error
   hipEvent_t *ev = ctx->ev[ctx->ev_head];
+  int n_slices = ctx->n_slices > 0 ? ctx->n_slices : 1;
+  n_slices = std::max(1, std::min(std::min(n_slices, (int)orbgpu_ctx::MAX_SLICES), n_frames));
   HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-  for (int l = 1; l < L; l++) launch_pyramid_level(ctx, n_frames, l);
-  HIP_TRY(hipEventRecord(ev[1], ctx->stream));
-  if (ctx->old_fast) {
-    launch_fast_score(ctx, n_frames);
-    HIP_TRY(hipEventRecord(ev[2], ctx->stream));
-    launch_cell_detect(ctx, n_frames);
-  } else {
-    launch_fast_cells(ctx, n_frames, nullptr);
-    HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+  for (int s = 0; s < n_slices; s++) {
+    const int f0 = (int)((long long)n_frames * s / n_slices), f1 = (int)((long long)n_frames * (s + 1) / n_slices);
+    const FrameSlice fs{f0, f1 - f0, s == 0 ? ctx->stream : ctx->slice_stream[s]};
+    const FrameSlice fb{f0, f1 - f0, ctx->slice_blur[s]};
+    hipEvent_t *sev = ctx->slice_ev[s];
+    const bool timed = s == 0;  // the stage timers follow slice 0
+    if (s > 0) HIP_TRY(hipStreamWaitEvent(fs.stream, ev[0], 0));  // fork: after everything already on the context's stream
+    for (int l = 1; l < L; l++) launch_pyramid_level(ctx, fs, l);
+    if (timed) HIP_TRY(hipEventRecord(ev[1], fs.stream));
+    launch_fast_cells(ctx, fs, nullptr);
+    if (timed) {
+      HIP_TRY(hipEventRecord(ev[2], fs.stream));
+      HIP_TRY(hipEventRecord(ev[3], fs.stream));
+    }
+    HIP_TRY(hipEventRecord(sev[0], fs.stream));
+    // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
+    // dependent rounds in levels x frames workgroups and leaves most of the chip idle
+    // (enqueued after the quadtree so that the quadtree's workgroups are placed first and the blur fills the rest)
+    if (launch_quadtree(ctx, fs, budget) != 0)
+      return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
+    if (timed) HIP_TRY(hipEventRecord(ev[4], fs.stream));
+    HIP_TRY(hipStreamWaitEvent(fb.stream, sev[0], 0));
+    if (timed) HIP_TRY(hipEventRecord(ev[7], fb.stream));
+    launch_blur(ctx, fb);
+    if (timed) HIP_TRY(hipEventRecord(ev[8], fb.stream));
+    HIP_TRY(hipEventRecord(sev[1], fb.stream));
+    HIP_TRY(hipStreamWaitEvent(fs.stream, sev[1], 0));
+    if (timed) HIP_TRY(hipEventRecord(ev[5], fs.stream));
+    launch_orient_describe(ctx, fs, d_kp, d_desc, capacity, d_n_out);
+    if (timed) HIP_TRY(hipEventRecord(ev[6], fs.stream));
+    if (s > 0) {  // join
+      HIP_TRY(hipEventRecord(sev[2], fs.stream));
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, sev[2], 0));
+    }
   }
-  HIP_TRY(hipEventRecord(ev[3], ctx->stream));
-  // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
-  // dependent rounds in 8 x n_frames workgroups and leaves most of the chip idle
-  // (enqueued after the quadtree so that the quadtree's workgroups are placed first and the blur fills the rest)
-  if (launch_quadtree(ctx, n_frames, budget) != 0)
-    return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
-  HIP_TRY(hipEventRecord(ev[4], ctx->stream));
-  HIP_TRY(hipStreamWaitEvent(ctx->stream_blur, ev[3], 0));
-  HIP_TRY(hipEventRecord(ev[7], ctx->stream_blur));
-  launch_blur(ctx, n_frames, ctx->stream_blur);
-  HIP_TRY(hipEventRecord(ev[8], ctx->stream_blur));
-  HIP_TRY(hipStreamWaitEvent(ctx->stream, ev[8], 0));
-  HIP_TRY(hipEventRecord(ev[5], ctx->stream));
-  launch_orient_describe(ctx, n_frames, d_kp, d_desc, capacity, d_n_out);
-  HIP_TRY(hipEventRecord(ev[6], ctx->stream));
+  HIP_TRY(hipEventRecord(ev[9], ctx->stream));  // every slice has finished
   HIP_TRY(hipMemcpyAsync(ctx->h_error_flag, ctx->d_error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipGetLastError());
   ctx->ev_head = (ctx->ev_head + 1) % ORBGPU_EV_SETS;
   ctx->ev_pending = std::min(ctx->ev_pending + 1, ORBGPU_EV_SETS);
   ctx->last_frames = n_frames;
   ctx->last_feature_count = feature_count;
+  ctx->last_slices = n_slices;
   return 0;
 }
 
@@ -269,7 +280,7 @@ int finish_pipeline(orbgpu_ctx *ctx) {
       for (int i = 0; i < 4; i++) acc[i] += elapsed(ev[i], ev[i + 1]);
       acc[4] += elapsed(ev[7], ev[8]);  // blur, on its own stream (overlaps the quadtree stage)
       acc[5] += elapsed(ev[5], ev[6]);
-      acc[6] += elapsed(ev[0], ev[6]);
+      acc[6] += elapsed(ev[0], ev[9]);
     }
     for (int i = 0; i < 7; i++) ctx->stage_ms[i] = acc[i] / (float)n;
     if (*ctx->h_error_flag != 0) {
@@ -335,8 +346,8 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   {
     const char *z = std::getenv("ORBGPU_NO_ZERO_COPY");
     ctx->no_zero_copy = z && z[0] == '1';
-    const char *o = std::getenv("ORBGPU_OLD_FAST");
-    ctx->old_fast = o && o[0] == '1';
+    const char *o = std::getenv("ORBGPU_SLICES");  // tuning aid: slices per batch, 0 / unset = automatic
+    ctx->n_slices = o ? std::atoi(o) : 0;
   }
   auto bail = [&](int rc) {
     g_create_error = ctx->err;
@@ -370,16 +381,16 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(match_noalloc_init(ctx->device));  // address of this GPU's copy of the fixed scratch array
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_blur, hipStreamNonBlocking));
+    for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
+      if (k > 0) HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_stream[k], hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_blur[k], hipStreamNonBlocking));
+      for (auto &e : ctx->slice_ev[k]) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     for (auto &set : ctx->ev)
       for (auto &ev : set) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(dmalloc(&ctx->d_pyr, B * g.frame_bytes + 256));
-    HIP_TRY(dmalloc(&ctx->d_score, B * g.frame_bytes + 256));
     HIP_TRY(dmalloc(&ctx->d_blur, B * g.frame_bytes + 256));
-    HIP_TRY(dmalloc(&ctx->d_nzmask, B * (size_t)g.mask_dwords_per_frame + 64));
-    HIP_TRY(hipMemsetAsync(ctx->d_nzmask, 0, (B * (size_t)g.mask_dwords_per_frame + 64) * sizeof(unsigned), ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_pyr, 0, B * g.frame_bytes + 256, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_score, 0, B * g.frame_bytes + 256, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_blur, 0, B * g.frame_bytes + 256, ctx->stream));
     HIP_TRY(dmalloc(&ctx->d_xtab, xt.size()));
     HIP_TRY(dmalloc(&ctx->d_ytab, yt.size()));
@@ -424,7 +435,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void *dptrs[] = {ctx->d_nzmask, ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
+  void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes,
                    ctx->d_error_flag, ctx->d_fast_groups};
@@ -436,7 +447,16 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   for (auto &set : ctx->ev)
     for (auto &ev : set)
       if (ev) (void)hipEventDestroy(ev);
-  if (ctx->stream_blur) (void)hipStreamDestroy(ctx->stream_blur);
+  for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
+    if (ctx->slice_stream[k]) (void)hipStreamSynchronize(ctx->slice_stream[k]);
+    if (ctx->slice_blur[k]) (void)hipStreamSynchronize(ctx->slice_blur[k]);
+  }
+  for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
+    for (auto &e : ctx->slice_ev[k])
+      if (e) (void)hipEventDestroy(e);
+    if (ctx->slice_stream[k]) (void)hipStreamDestroy(ctx->slice_stream[k]);
+    if (ctx->slice_blur[k]) (void)hipStreamDestroy(ctx->slice_blur[k]);
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -472,6 +492,13 @@ int orbgpu_set_stream(orbgpu_ctx *ctx, void *stream) {
   int rc = finish_pipeline(ctx);
   ctx->stream = stream ? static_cast<hipStream_t>(stream) : ctx->own_stream;
   return rc;
+}
+
+int orbgpu_set_batch_slices(orbgpu_ctx *ctx, int32_t n_slices) {
+  if (!ctx || n_slices < 0 || n_slices > orbgpu_ctx::MAX_SLICES) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->n_slices = n_slices;
+  return ORBGPU_OK;
 }
 
 int orbgpu_wait_event(orbgpu_ctx *ctx, void *event) {
@@ -635,20 +662,21 @@ int orbgpu_debug_dump(orbgpu_ctx *ctx, int32_t frame, uint8_t *pyramid, uint8_t 
   const DeviceGeom &g = ctx->geom;
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (score && !ctx->old_fast) {
-    // the product path keeps no score map: re-run the fused kernel on the (still resident) pyramid of the last call with
-    // its DUMP switch, which scatters every non-zero score into d_score
-    HIP_TRY(hipMemsetAsync(ctx->d_score, 0, (size_t)ctx->last_frames * g.frame_bytes, ctx->stream));
-    launch_fast_cells(ctx, ctx->last_frames, ctx->d_score);
+  if (score) {
+    // the product path keeps no score map: re-run the fused kernel on the (still resident) pyramid of that frame with
+    // its DUMP switch, which scatters every non-zero score into a one-frame slab (allocated by the first such dump)
+    if (!ctx->d_score) HIP_TRY(dmalloc(&ctx->d_score, (size_t)g.frame_bytes + 256));
+    HIP_TRY(hipMemsetAsync(ctx->d_score, 0, g.frame_bytes, ctx->stream));
+    launch_fast_cells(ctx, FrameSlice{frame, 1, ctx->stream}, ctx->d_score);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   std::vector<uint8_t> slab(g.frame_bytes);
-  const uint8_t *srcs[3] = {ctx->d_pyr, ctx->d_score, ctx->d_blur};
+  const uint8_t *srcs[3] = {ctx->d_pyr + (size_t)frame * g.frame_bytes, ctx->d_score, ctx->d_blur + (size_t)frame * g.frame_bytes};
   uint8_t *dsts[3] = {pyramid, score, blurred};
   for (int k = 0; k < 3; k++) {
     if (!dsts[k]) continue;
-    HIP_TRY(hipMemcpy(slab.data(), srcs[k] + (size_t)frame * g.frame_bytes, g.frame_bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(slab.data(), srcs[k], g.frame_bytes, hipMemcpyDeviceToHost));
     if (k == 0 && ctx->lvl0.base)  // level 0 was read in place
       HIP_TRY(hipMemcpy(slab.data() + g.lv[0].off, ctx->lvl0.base + (size_t)frame * (size_t)ctx->lvl0.frame_stride,
                         (size_t)g.lv[0].pitch * g.lv[0].h, hipMemcpyDeviceToHost));

@@ -275,11 +275,15 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
 
 }  // namespace
 
-void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
+void launch_orient_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                             int *d_n_out) {
-  dim3 grid((c->geom.kps_per_frame + KPG - 1) / KPG * xcd_frames(n_frames));
-  hipLaunchKernelGGL(k_orient_describe, grid, dim3(64 * KPB), 0, c->stream, c->d_pyr, c->d_blur, c->geom, c->d_kp_xy,
-                     c->d_kp_count, d_kp, d_desc, capacity, d_n_out, n_frames, c->lvl0, c->d_error_flag);
+  const DeviceGeom &g = c->geom;
+  dim3 grid((g.kps_per_frame + KPG - 1) / KPG * xcd_frames(fs.n));
+  const size_t off = (size_t)fs.f0 * g.frame_bytes;
+  hipLaunchKernelGGL(k_orient_describe, grid, dim3(64 * KPB), 0, fs.stream, c->d_pyr + off, c->d_blur + off, g,
+                     c->d_kp_xy + (size_t)fs.f0 * g.kps_per_frame, c->d_kp_count + (size_t)fs.f0 * g.levels,
+                     d_kp + (size_t)fs.f0 * capacity, d_desc + (size_t)fs.f0 * capacity * 32, capacity, d_n_out + fs.f0, fs.n,
+                     slice_lvl0(c, fs), c->d_error_flag);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   const size_t base = (size_t)frame * g.frame_bytes + L.off;
   const uint8_t *src = level_src(pyr, g, lvl0, frame, l, L.off);
 
-  stage_tile<BT_ROWS, true>(tile, src, L.w, L.h, L.pitch, x0, y0);
+  stage_tile<BT_ROWS>(tile, src, L.w, L.h, L.pitch, x0, y0);
   __syncthreads();
 
   // horizontal pass: task = (row pair, 4-pixel group)
@@ -261,15 +261,16 @@ void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t fr
                      c->geom.frame_bytes, L.w, L.h, L.pitch, aligned16);
 }
 
-void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level) {
+void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level) {
   const LevelGeom &D = c->geom.lv[level];
-  dim3 grid(((D.w + TILE_W - 1) / TILE_W) * ((D.h + RS_TILE_H - 1) / RS_TILE_H) * xcd_frames(n_frames));
+  dim3 grid(((D.w + TILE_W - 1) / TILE_W) * ((D.h + RS_TILE_H - 1) / RS_TILE_H) * xcd_frames(fs.n));
   const size_t lds = (size_t)c->rs_pitch[level] * c->rs_rows[level];
-  hipLaunchKernelGGL(k_resize_level, grid, dim3(256), lds, c->stream, c->d_pyr, c->geom, level, c->d_xtab, c->d_ytab,
-                     c->rs_pitch[level], n_frames, c->lvl0);
+  hipLaunchKernelGGL(k_resize_level, grid, dim3(256), lds, fs.stream, c->d_pyr + (size_t)fs.f0 * c->geom.frame_bytes, c->geom,
+                     level, c->d_xtab, c->d_ytab, c->rs_pitch[level], fs.n, slice_lvl0(c, fs));
 }
 
-void launch_blur(const orbgpu_ctx *c, int n_frames, hipStream_t stream) {
-  dim3 grid(c->geom.btiles_per_frame * xcd_frames(n_frames));
-  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, stream, c->d_pyr, c->d_blur, c->geom, n_frames, c->lvl0);
+void launch_blur(const orbgpu_ctx *c, FrameSlice fs) {
+  dim3 grid(c->geom.btiles_per_frame * xcd_frames(fs.n));
+  const size_t off = (size_t)fs.f0 * c->geom.frame_bytes;
+  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, fs.stream, c->d_pyr + off, c->d_blur + off, c->geom, fs.n, slice_lvl0(c, fs));
 }

@@ -678,16 +678,17 @@ size_t quadtree_node_bytes(int node_cap) {
 }
 size_t quadtree_lds_bytes(int node_cap) { return sizeof(unsigned) * 2 * QT_LDS_KEYS + quadtree_node_bytes(node_cap); }
 
-int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
+int launch_quadtree(const orbgpu_ctx *c, FrameSlice fs, const int *budget) {
+  const int n_frames = fs.n;
   const DeviceGeom &g = c->geom;
   QtArgs a{};
-  a.cells = c->d_cells;
-  a.cands = c->d_cands;
-  a.buf_a = c->d_cands_packed;
-  a.buf_b = c->d_cands_tmp;
-  a.cell_prefix = c->d_cell_prefix;
-  a.kp_xy = c->d_kp_xy;
-  a.kp_count = c->d_kp_count;
+  a.cells = c->d_cells + (size_t)fs.f0 * g.cells_per_frame;
+  a.cands = c->d_cands + (size_t)fs.f0 * g.cands_per_frame;
+  a.buf_a = c->d_cands_packed + (size_t)fs.f0 * g.cands_per_frame;
+  a.buf_b = c->d_cands_tmp + (size_t)fs.f0 * g.cands_per_frame;
+  a.cell_prefix = c->d_cell_prefix + (size_t)fs.f0 * g.cells_per_frame;
+  a.kp_xy = c->d_kp_xy + (size_t)fs.f0 * g.kps_per_frame;
+  a.kp_count = c->d_kp_count + (size_t)fs.f0 * g.levels;
   a.error_flag = c->d_error_flag;
   int cap = 0;
   for (int l = 0; l < g.levels; l++) {
@@ -701,8 +702,8 @@ int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
   const bool nodes_global = lds > ORBGPU_QT_LDS_LIMIT;
   if (nodes_global) {
     if (!c->d_qt_nodes) return -1;  // orbgpu_create allocates it for such contexts
-    a.node_scratch = c->d_qt_nodes;
     a.node_bytes = quadtree_node_bytes(cap);
+    a.node_scratch = c->d_qt_nodes + (size_t)fs.f0 * g.levels * a.node_bytes;
     lds = sizeof(unsigned) * 2 * QT_LDS_KEYS + 64;
   }
   // a level of a VGA-class image holds a few thousand candidates: 256 threads keep its short dependent rounds cheap
@@ -722,11 +723,11 @@ int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget) {
   if (profile && hipMalloc(&a.prof, 64 * 8) == hipSuccess) (void)hipMemset(a.prof, 0, 64 * 8);
   const dim3 grid(g.levels, n_frames);
   if (nodes_global) {
-    if (big) hipLaunchKernelGGL((k_quadtree<1024, true>), grid, dim3(1024), lds, c->stream, g, a);
-    else hipLaunchKernelGGL((k_quadtree<256, true>), grid, dim3(256), lds, c->stream, g, a);
+    if (big) hipLaunchKernelGGL((k_quadtree<1024, true>), grid, dim3(1024), lds, fs.stream, g, a);
+    else hipLaunchKernelGGL((k_quadtree<256, true>), grid, dim3(256), lds, fs.stream, g, a);
   } else {
-    if (big) hipLaunchKernelGGL((k_quadtree<1024, false>), grid, dim3(1024), lds, c->stream, g, a);
-    else hipLaunchKernelGGL((k_quadtree<256, false>), grid, dim3(256), lds, c->stream, g, a);
+    if (big) hipLaunchKernelGGL((k_quadtree<1024, false>), grid, dim3(1024), lds, fs.stream, g, a);
+    else hipLaunchKernelGGL((k_quadtree<256, false>), grid, dim3(256), lds, fs.stream, g, a);
   }
   if (a.prof) {  // debugging aid: synchronous, prints the phase times of one workgroup
     unsigned long long h[64];

@@ -30,9 +30,7 @@ struct LevelGeom {
   int cell_off;                    // first cell of this level in a frame's cell table
   int cand_off, cand_cap;          // candidate sub-pool (u32 entries) inside a frame's candidate slab
   int kp_off, kp_cap;              // keypoint slots of this level inside a frame's keypoint slab
-  int ftile_off;                   // first 128x32 tile of this level in the all-level tile index (FAST)
   int btile_off;                   // first tile of this level in the blur kernel's tile index (128 x ORBGPU_BLUR_TILE_H)
-  int mask_off, mask_pitch;        // non-zero-score bit plane: first dword of the level, dwords per row
   int xtab_off, ytab_off;          // resize coefficient tables (entries)
   int kp_size;                     // int(31 * scale_factors_[l])
   float scale_f;                   // (float)scale_factors_[l]
@@ -45,11 +43,9 @@ struct DeviceGeom {
   int cells_per_frame;
   int cands_per_frame;
   int kps_per_frame;      // sum of kp_cap
-  int ftiles_per_frame;
   int btiles_per_frame;
-  int mask_dwords_per_frame;
   // compact copies of the per-level offsets (INT_MAX beyond the last level): one wide scalar load finds a level
-  int kp_offs[ORBGPU_MAX_LEVELS], ftile_offs[ORBGPU_MAX_LEVELS], cell_offs[ORBGPU_MAX_LEVELS];
+  int kp_offs[ORBGPU_MAX_LEVELS], cell_offs[ORBGPU_MAX_LEVELS];
   LevelGeom lv[ORBGPU_MAX_LEVELS];
 };
 
@@ -103,20 +99,23 @@ struct orbgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // where the context enqueues: its own stream, or the caller's (orbgpu_set_stream)
   hipStream_t own_stream = nullptr;
-  hipStream_t stream_blur = nullptr;  // the blur runs beside the (latency-bound) quadtree kernel
+  static constexpr int MAX_SLICES = 4;
+  hipStream_t slice_stream[MAX_SLICES]{};  // slices 1.. of a batch (slice 0 runs on `stream`)
+  hipStream_t slice_blur[MAX_SLICES]{};    // the blur of a slice runs beside its (latency-bound) quadtree kernel
+  hipEvent_t slice_ev[MAX_SLICES][3]{};    // fork / blur-may-start / slice-done
   std::mutex mu;
   std::string err;
 
   // device slabs, sized for max_batch frames
-  uint8_t *d_pyr = nullptr, *d_score = nullptr, *d_blur = nullptr;
+  uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+  uint8_t *d_score = nullptr;     // score map of orbgpu_debug_dump only: allocated by the first dump that asks for it
   Level0Src lvl0{nullptr, 0};     // where the last extract call's level 0 lives (kernel argument of that call)
   mutable size_t qt_lds_configured[2] = {0, 0};  // dynamic-LDS limit already raised for k_quadtree<256> / <1024>
   bool no_zero_copy = false;      // ORBGPU_NO_ZERO_COPY=1: always copy level 0 into the slab (cross-check path)
-  unsigned *d_nzmask = nullptr;   // [frame][mask_dwords_per_frame]: bit x of row y set iff score(x, y) != 0
   short *d_fast_groups = nullptr; // FastGroup table of k_fast_cells (level, cell row, first cell, cells), one frame's worth
   int n_fast_groups = 0;
   int fast_lds_rows = 0;          // tallest cell of any level: sizes the dynamic LDS of k_fast_cells
-  bool old_fast = false;          // ORBGPU_OLD_FAST=1: score map + k_cell_detect (A/B measurements)
+  int n_slices = 1;               // slices a batch is cut into (ORBGPU_SLICES overrides)
   XTab *d_xtab = nullptr;
   YTab *d_ytab = nullptr;
   CellEntry *d_cells = nullptr;   // [frame][cells_per_frame]
@@ -144,12 +143,13 @@ struct orbgpu_ctx {
   void *d_match_scratch = nullptr;
   size_t match_scratch_bytes = 0;
 
-  hipEvent_t ev[ORBGPU_EV_SETS][9]{};  // stage boundaries of the last ORBGPU_EV_SETS extract calls (ring);
-                                       // [7], [8] bracket the blur on stream_blur
+  hipEvent_t ev[ORBGPU_EV_SETS][10]{};  // stage boundaries of the last ORBGPU_EV_SETS extract calls (ring);
+                                       // [7], [8] bracket the blur on its own stream, [9] = all slices joined
   int ev_head = 0, ev_pending = 0;
   float stage_ms[7]{};
   int last_frames = 0;
   int last_feature_count = 0;
+  int last_slices = 1;
 };
 
 // a vocabulary tree resident on the device of the context that created it
@@ -166,21 +166,27 @@ int fail(orbgpu_ctx *ctx, int code, const std::string &msg);
 int fail_hip(orbgpu_ctx *ctx, hipError_t e, const char *expr, const char *file, int line);
 
 // ---- kernel launchers (each defined next to its kernels) ----
-void launch_pyramid_level(const orbgpu_ctx *c, int n_frames, int level);
-void launch_fast_score(const orbgpu_ctx *c, int n_frames);
-void launch_cell_detect(const orbgpu_ctx *c, int n_frames);
+// The extraction kernels work on a slice of the batch -- frames f0 .. f0 + n - 1 of every per-frame array -- on the
+// slice's stream: a batch is cut into a few slices that run side by side (run_pipeline), so that the latency-bound
+// stages of one slice fill the issue slots the instruction-bound stages of another leave
+struct FrameSlice { int f0, n; hipStream_t stream; };
+inline Level0Src slice_lvl0(const orbgpu_ctx *c, FrameSlice fs) {
+  return c->lvl0.base ? Level0Src{c->lvl0.base + (size_t)fs.f0 * (size_t)c->lvl0.frame_stride, c->lvl0.frame_stride} : c->lvl0;
+}
+void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level);
 // fused FAST score + cell NMS (k_fast.hip); score_dump != nullptr: also scatter the non-zero scores into that slab
+// (laid out like the slice: its frame 0 is frame f0 of the batch)
 int build_fast_groups(const DeviceGeom &g, std::vector<short> &table);
-void launch_fast_cells(const orbgpu_ctx *c, int n_frames, uint8_t *score_dump);
-void launch_blur(const orbgpu_ctx *c, int n_frames, hipStream_t stream);
-void launch_orient_describe(const orbgpu_ctx *c, int n_frames, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
+void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump);
+void launch_blur(const orbgpu_ctx *c, FrameSlice fs);
+void launch_orient_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                             int *d_n_out);
 void launch_keypoint_geometry(const orbgpu_ctx *c, const orbgpu_camera &cam, const orbgpu_keypoint *d_kp, const int *d_n,
                               int n_frames, int capacity, double *d_undist, double *d_unproj, uint8_t *d_ok);
 void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t frame_stride, int stride, int n_frames);
 
 // device quadtree (k_quadtree.hip); budget = per-level feature budget.  Returns 0 or -1 (LDS too large)
-int launch_quadtree(const orbgpu_ctx *c, int n_frames, const int *budget);
+int launch_quadtree(const orbgpu_ctx *c, FrameSlice fs, const int *budget);
 size_t quadtree_lds_bytes(int node_cap);
 // dynamic LDS the quadtree kernel may ask for: the CU's 160 KB less its static arrays (scan sums, partition counters)
 constexpr size_t ORBGPU_QT_LDS_LIMIT = 156 * 1024;

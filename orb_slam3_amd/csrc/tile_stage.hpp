@@ -1,5 +1,5 @@
-// LDS staging of a 128-pixel-wide image tile with a 4-pixel column apron and a 3-row apron, shared by the FAST
-// score and the blur kernels.  One wave per staged row (4 waves -> rows w, w+4, ...), lane = aligned dword column
+// LDS staging of a 128-pixel-wide image tile with a 4-pixel column apron and a 3-row apron, used by the blur
+// kernel.  One wave per staged row (4 waves -> rows w, w+4, ...), lane = aligned dword column
 // (34 of 64 lanes), so the row index and its border handling are wave-uniform (scalar ALU) and the vector ALU only
 // forms one address per row.  All loads of a wave are issued before the first LDS write.
 #pragma once
@@ -29,10 +29,9 @@ __device__ __forceinline__ bool xcd_item_frame(int items_per_frame, int n_frames
 
 constexpr int STAGE_DW = 34;  // dwords per staged row: columns x0-4 .. x0+131
 
-// REFLECT = false: bytes outside the image read as 0 (FAST never scores a ring that touches them).
-// REFLECT = true : BORDER_REFLECT_101 on rows and on the 3 columns next to each image edge (further columns of the
-//                  apron are never used and hold unspecified image bytes).
-template <int ROWS, bool REFLECT>
+// BORDER_REFLECT_101 on rows and on the 3 columns next to each image edge (further columns of the apron are never used
+// and hold unspecified image bytes).
+template <int ROWS>
 __device__ __forceinline__ void stage_tile(unsigned *__restrict__ tile, const uint8_t *__restrict__ src, int w, int h,
                                            int pitch, int x0, int y0) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -44,25 +43,7 @@ __device__ __forceinline__ void stage_tile(unsigned *__restrict__ tile, const ui
   // tiles whose staged rows all lie inside the image (the common case) take a path without per-row border logic:
   // one row pointer, advanced by 4 rows per step
   const bool rows_inside = y0 >= 3 && y0 - 3 + ROWS <= h;  // wave-uniform
-  if (!REFLECT) {
-    const bool col_ok = gx >= 0 && gx < pitch;
-    if (rows_inside) {
-      const uint8_t *row = src + (size_t)(y0 - 3 + wave) * pitch + gx;
-#pragma unroll
-      for (int k = 0; k < NR; k++) {
-        v[k] = 0;
-        if (wave + 4 * k < ROWS && col_ok) v[k] = *reinterpret_cast<const unsigned *>(row + (size_t)(4 * k) * pitch);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NR; k++) {
-        const int r = wave + 4 * k;
-        const int gy = y0 - 3 + r;
-        v[k] = 0;
-        if (r < ROWS && gy >= 0 && gy < h && col_ok) v[k] = *reinterpret_cast<const unsigned *>(src + (size_t)gy * pitch + gx);
-      }
-    }
-  } else {
+  {
     // wave-uniform: does any lane of this tile need a byte from outside [0, w)?
     const bool edge = x0 == 0 || x0 + 128 + 4 > w;
     if (!edge && rows_inside) {
