@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < (nrow + 2) * (FC_TP / 4); i += 256) reinterpret_cast<uint4 *>(stile)[i] = z4;
     if (tid < nrow * FC_MAXK) reinterpret_cast<uint4 *>(rmask)[tid] = z4;
-    if (tid == 0) *q_count = 0;
+    if (tid < 2) q_count[tid] = 0;  // [0] packed queue counts, [1] bit j: cell j falls back to minThFAST
     if (tid < FC_TP) {
       unsigned m = 0;
 #pragma unroll
@@ -203,16 +203,21 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
 
   const int t_lo = g.fast_min, t_hi = g.fast_init;
   const float inv_ncg = 1.0f / (float)ncg;
-  // candidate <=> max(v - max_k min(pair_k), min_k max(pair_k) - v) > t: with saturating u16 arithmetic the sum
-  // max(...) + (255 - t) has bit 8 set exactly then
-  const unsigned short bias = (unsigned short)(255 - t_lo);
-  const u16x2 bias2 = {bias, bias};
+  // candidate at threshold t <=> M = max(v - max_k min(pair_k), min_k max(pair_k) - v) > t: with saturating u16
+  // arithmetic M + (255 - t) has bit 8 set exactly then.  Two thresholds, one M.
+  const unsigned short bias_lo = (unsigned short)(255 - t_lo), bias_hi = (unsigned short)(255 - t_hi);
+  const u16x2 bias_lo2 = {bias_lo, bias_lo}, bias_hi2 = {bias_hi, bias_hi};
   // the lane's quad of pass k is q = tid + 256 k = (row ry, quad column cq), advanced by (d_r, d_c) per pass
   int ry = div_small(tid, ncg, inv_ncg), cq = tid - ry * ncg;
   const int d_r = __builtin_amdgcn_readfirstlane(div_small(256, ncg, inv_ncg)), d_c = 256 - d_r * ncg;
+  const int qcap = lds_rows * FC_QPITCH;
   // ---- phase 1 + push, 8 passes (2048 quads) at a time ------------------------------------------------------
+  // Survivors of the quick test at iniThFAST go to the front of the queue, those that only pass at minThFAST to its
+  // back: a pixel scoring below iniThFAST can neither be kept nor suppress anything in a cell that keeps a corner at
+  // iniThFAST (NMS is a strict > against a value >= iniThFAST), so the back of the queue is only ever scored for cells
+  // that fall back to minThFAST.
   for (int qbase = 0; qbase < nq4; qbase += 2048) {
-    unsigned acc = 0;  // bit 8 * p + pass: pixel p of this lane's quad in pass `pass` may be a corner
+    unsigned acc_lo = 0, acc_hi = 0;  // bit 8 * p + pass: pixel p of this lane's quad in pass `pass` may be a corner
     const int npass = min(8, (nq4 - qbase + 255) >> 8);
 #pragma unroll 1
     for (int pass = 0; pass < npass; pass++) {
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
         for (int j = 0; j < 7; j++)
 #pragma unroll
           for (int c = 0; c < 3; c++) w[j][c] = tw[j * FC_TP + c];
-        unsigned hi_bytes[2];
+        unsigned lo_bytes[2], hi_bytes[2];
 #pragma unroll
         for (int pr = 0; pr < 2; pr++) {
           u16x2 r[16];
@@ -247,11 +252,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
           }
           const u16x2 dk = __builtin_elementwise_sub_sat(v, mx_of_min);   // how far below the centre a dark arc can sit
           const u16x2 br = __builtin_elementwise_sub_sat(mn_of_max, v);   // how far above a bright one
-          hi_bytes[pr] = as_u32(__builtin_elementwise_max(dk, br) + bias2);
+          const u16x2 m = __builtin_elementwise_max(dk, br);
+          lo_bytes[pr] = as_u32(m + bias_lo2);
+          hi_bytes[pr] = as_u32(m + bias_hi2);
         }
         // bytes 1 and 3 of both results: 0 or 1 per pixel, pixel p in byte p
-        const unsigned flags = __builtin_amdgcn_perm(hi_bytes[1], hi_bytes[0], 0x07050301u) & colmask[cq];
-        acc |= flags << pass;
+        const unsigned cm = colmask[cq];
+        acc_lo |= (__builtin_amdgcn_perm(lo_bytes[1], lo_bytes[0], 0x07050301u) & cm) << pass;
+        acc_hi |= (__builtin_amdgcn_perm(hi_bytes[1], hi_bytes[0], 0x07050301u) & cm) << pass;
       }
       cq += d_c;
       ry += d_r;
@@ -262,31 +270,47 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     }
     // ---- push the survivors as (quad << 2 | pixel): one LDS atomic per wave; the order inside the queue is free ----
     {
-      const int cnt = __popc(acc);  // 0..32
+      acc_lo &= ~acc_hi;  // only at minThFAST
+      const int cnt = __popc(acc_hi) | (__popc(acc_lo) << 16);  // both scans at once
       const int incl = wave_incl_scan(cnt);
       const int tot = __builtin_amdgcn_readlane(incl, 63);
       if (tot) {
         int basep = 0;
         if (lane == 0) basep = atomicAdd(q_count, tot);
-        int pos = __builtin_amdgcn_readfirstlane(basep) + incl - cnt;
+        const int at = __builtin_amdgcn_readfirstlane(basep) + incl - cnt;
+        int pos_hi = at & 0xffff, pos_lo = qcap - 1 - (at >> 16);
         const unsigned qt = (unsigned)(qbase + tid) << 2;
-        unsigned m = acc;
+        unsigned m = acc_hi;
         while (m) {
           const int bit = __ffs(m) - 1;
           m &= m - 1;
-          queue[pos++] = (unsigned short)(qt + ((unsigned)(bit & 7) << 10) + ((unsigned)bit >> 3));
+          queue[pos_hi++] = (unsigned short)(qt + ((unsigned)(bit & 7) << 10) + ((unsigned)bit >> 3));
+        }
+        m = acc_lo;
+        while (m) {
+          const int bit = __ffs(m) - 1;
+          m &= m - 1;
+          queue[pos_lo--] = (unsigned short)(qt + ((unsigned)(bit & 7) << 10) + ((unsigned)bit >> 3));
         }
       }
     }
   }
   __syncthreads();
-  // ---- phase 2: full score of the survivors -> score tile; the queue entry becomes (row << 8 | column) ------------
-  const int nq = *q_count;
+  const int n_hi = *q_count & 0xffff, n_lo = *q_count >> 16;
   const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
   uint8_t *sb = reinterpret_cast<uint8_t *>(stile);
-  for (int q = tid; q < nq; q += 256) {
+  const int bnd0 = X0 - xs0;  // tile column - 4 of the first pixel of cell j0
+  // full 9-arc score of queue entry q -> score tile; the entry becomes (row << 8 | column).  need_mask: cells whose
+  // entries are scored (bit j), all of them for the front of the queue
+  auto score_entry = [&](int q, unsigned need_mask) {
     const int e = queue[q];
     const int ey = div_small(e >> 2, ncg, inv_ncg), cx = 4 * ((e >> 2) - ey * ncg) + (e & 3);
+    queue[q] = (unsigned short)((ey << 8) | cx);
+    if (need_mask != 0xfu) {
+      const int rel = cx - bnd0;
+      const int j = (rel >= L.wcell) + (rel >= 2 * L.wcell) + (rel >= 3 * L.wcell);
+      if (!((need_mask >> j) & 1u)) return;
+    }
     const uint8_t *c = tb + (ey + 3) * FC_TPB + cx + 4;
     constexpr int RP = FC_TPB;
     int r[16];
@@ -295,61 +319,46 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     r[8] = c[-3 * RP];      r[9] = c[-3 * RP - 1];  r[10] = c[-2 * RP - 2]; r[11] = c[-RP - 3];
     r[12] = c[-3];          r[13] = c[RP - 3];      r[14] = c[2 * RP - 2];  r[15] = c[3 * RP - 1];
     const int sc = fast_score16_full((int)c[0], r, t_lo);
-    queue[q] = (unsigned short)((ey << 8) | cx);
     if (sc) {
       sb[(ey + 1) * FC_TPB + cx + 4] = (uint8_t)sc;
       if (DUMP) score_dump[(size_t)frame * g.frame_bytes + L.off + (size_t)(Y0 + ey) * L.pitch + (xs0 + cx)] = (uint8_t)sc;
     }
-  }
-  __syncthreads();
-  // ---- phase 3: 3x3 NMS inside the pixel's own cell; one sweep serves both thresholds ------------------------------
-  const int bnd0 = X0 - xs0;  // tile column - 4 of the first pixel of cell j0
-  for (int q = tid; q < nq; q += 256) {
+  };
+  // 3x3 NMS of (decoded) queue entry q inside the pixel's own cell; survivors with score >= t_keep in the cells of
+  // need_mask set their bit in the cell's row mask `which` (0: kept at minThFAST, 2: kept at iniThFAST)
+  auto nms_entry = [&](int q, int t_keep, unsigned need_mask, int which) {
     const int e = queue[q];
     const int ey = e >> 8, cx = e & 255;
     const uint8_t *c = sb + (ey + 1) * FC_TPB + cx + 4;
     const int v = c[0];
-    if (v == 0) continue;
+    if (v < t_keep) return;  // the score tile holds 0 below minThFAST
     const int rel = cx - bnd0;
     const int j = (rel >= L.wcell) + (rel >= 2 * L.wcell) + (rel >= 3 * L.wcell);
+    if (!((need_mask >> j) & 1u)) return;
     const int xx = rel - j * L.wcell;  // column inside the cell
     int nl = vmax3(c[-FC_TPB - 1], c[-1], c[FC_TPB - 1]);
     int nr = vmax3(c[-FC_TPB + 1], c[1], c[FC_TPB + 1]);
     nl = xx == 0 ? 0 : nl;                  // "NMS does not see across the seam"
     nr = xx == L.wcell - 1 ? 0 : nr;        // (beyond X1 nothing was scored)
     const int nm = vmax3(c[-FC_TPB], c[FC_TPB], max(nl, nr));
-    if (v > nm) {                           // the score tile holds 0 below fast_min
-      unsigned *mrow = rmask + ((ey * FC_MAXK + j) << 2) + (xx >> 5);
-      atomicOr(mrow, 1u << (xx & 31));
-      if (v >= t_hi) atomicOr(mrow + 2, 1u << (xx & 31));
-    }
-  }
-  __syncthreads();
-  // ---- phase 4: wave = cell, lane = row; fallback decided per cell AFTER NMS (orb_feature_extractor.cpp:263-266) ----
-  if (wave >= G.ncell) return;
-  {
-    const int j = wave;
-    const int cx0 = X0 + j * L.wcell, cx1 = min(cx0 + L.wcell - 1, X1);
-    const int ci = G.row * L.ncols + G.j0 + j;
-    if (cx1 < cx0) {
-      if (lane == 0) ce[j] = CellEntry{0, 0};
-      return;
-    }
-    uint4 mk = make_uint4(0, 0, 0, 0);
-    if (lane < nrow) mk = reinterpret_cast<const uint4 *>(rmask)[lane * FC_MAXK + j];
-    const int c_lo = __popc(mk.x) + __popc(mk.y), c_hi = __popc(mk.z) + __popc(mk.w);
-    const int cnt2 = (c_hi << 16) | c_lo;  // both scans at once (a cell holds < 2^12 survivors)
-    const int incl = wave_incl_scan(cnt2);
-    const int tot = __builtin_amdgcn_readlane(incl, 63);
-    const bool use_hi = (tot >> 16) > 0;
-    const int total = use_hi ? (tot >> 16) : (tot & 0xffff);
+    if (v > nm) atomicOr(rmask + ((ey * FC_MAXK + j) << 2) + which + (xx >> 5), 1u << (xx & 31));
+  };
+  // wave = cell, lane = row: survivors of the cell's row masks `which` in raster order -> the cell's fixed slot of the
+  // candidate pool; returns the number written (wave-uniform)
+  auto emit_cell = [&](int j, int which) -> int {
+    const int cx0 = X0 + j * L.wcell;
+    uint2 mk = make_uint2(0, 0);
+    if (lane < nrow) mk = *reinterpret_cast<const uint2 *>(rmask + ((lane * FC_MAXK + j) << 2) + which);
+    const int cnt = __popc(mk.x) + __popc(mk.y);
+    const int incl = wave_incl_scan(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) return 0;
     // every cell owns a fixed slot of ceil(wCell/2) * ceil(hCell/2) entries in its level's sub-pool: NMS survivors
     // are never adjacent, so the slot cannot overflow and no atomic is needed
-    const int basei = ci * cell_slot;
+    const int basei = (G.row * L.ncols + G.j0 + j) * cell_slot;
     if (lane == 0) ce[j] = CellEntry{basei, total};
-    if (total == 0) return;
-    unsigned long long bits = use_hi ? (((unsigned long long)mk.w << 32) | mk.z) : (((unsigned long long)mk.y << 32) | mk.x);
-    int pos = use_hi ? ((incl - cnt2) >> 16) : ((incl - cnt2) & 0xffff);
+    unsigned long long bits = ((unsigned long long)mk.y << 32) | mk.x;
+    int pos = incl - cnt;
     unsigned *out = cands + (size_t)frame * g.cands_per_frame + L.cand_off + basei;
     const uint8_t *srow = sb + (lane + 1) * FC_TPB + 4 + (cx0 - xs0);
     const unsigned ybits = (unsigned)(Y0 + lane - ORB_MIN_BORDER) << 12;
@@ -358,6 +367,39 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
       bits &= bits - 1;
       out[pos++] = (unsigned)(cx0 + xx - ORB_MIN_BORDER) | ybits | ((unsigned)srow[xx] << 24);
     }
+    return total;
+  };
+
+  // ---- iniThFAST: score the front of the queue, NMS, emit ---------------------------------------------------------
+  for (int q = tid; q < n_hi; q += 256) score_entry(q, 0xfu);
+  __syncthreads();
+  for (int q = tid; q < n_hi; q += 256) nms_entry(q, t_hi, 0xfu, 2);
+  __syncthreads();
+  if (wave < G.ncell) {
+    // a cell without columns (beyond the last detection column) holds nothing at either threshold
+    const bool has_cols = X0 + wave * L.wcell <= X1;
+    const int total = has_cols ? emit_cell(wave, 2) : 0;
+    if (total == 0) {
+      if (has_cols) {
+        if (lane == 0) atomicOr(reinterpret_cast<unsigned *>(q_count + 1), 1u << wave);  // falls back to minThFAST
+      } else if (lane == 0) {
+        ce[wave] = CellEntry{0, 0};
+      }
+    }
+  }
+  __syncthreads();
+  // ---- minThFAST for the cells that kept nothing (orb_feature_extractor.cpp:263-266: decided per cell AFTER NMS) ----
+  const unsigned fallback = (unsigned)q_count[1];
+  const unsigned score_mask = DUMP ? 0xfu : fallback;
+  if (score_mask == 0) return;
+  for (int q = qcap - 1 - tid; q >= qcap - n_lo; q -= 256) score_entry(q, score_mask);
+  if (fallback == 0) return;
+  __syncthreads();
+  for (int q = tid; q < n_hi; q += 256) nms_entry(q, 1, fallback, 0);
+  for (int q = qcap - 1 - tid; q >= qcap - n_lo; q -= 256) nms_entry(q, 1, fallback, 0);
+  __syncthreads();
+  if (wave < G.ncell && ((fallback >> wave) & 1u)) {
+    if (emit_cell(wave, 0) == 0 && lane == 0) ce[wave] = CellEntry{(G.row * L.ncols + G.j0 + wave) * cell_slot, 0};
   }
 }
 
