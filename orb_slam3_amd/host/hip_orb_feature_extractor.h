@@ -43,8 +43,12 @@ class HipORBFeatureExtractor : public IFeatureExtractor {
       level_sigma2_[i] = g.sigma2[i];
     }
     max_features_ = max_features;
+    if (!DefaultContextSlot()) DefaultContextSlot() = ctx_;
   }
-  ~HipORBFeatureExtractor() override { orbgpu_destroy(ctx_); }
+  ~HipORBFeatureExtractor() override {
+    if (DefaultContextSlot() == ctx_) DefaultContextSlot() = nullptr;
+    orbgpu_destroy(ctx_);
+  }
   HipORBFeatureExtractor(const HipORBFeatureExtractor &) = delete;
   HipORBFeatureExtractor & operator=(const HipORBFeatureExtractor &) = delete;
 
@@ -117,8 +121,16 @@ class HipORBFeatureExtractor : public IFeatureExtractor {
   }
 
   orbgpu_ctx * context() const { return ctx_; }
+  // The context of the process's first live extractor: what callers without an extractor argument use
+  // (features::matching::OrientationValidator has the reference's two-argument constructor).  The reference has one
+  // extractor per process, owned by the Atlas (map/atlas.h:44).
+  static orbgpu_ctx * DefaultContext() { return DefaultContextSlot(); }
 
  private:
+  static orbgpu_ctx *& DefaultContextSlot() {
+    static orbgpu_ctx * slot = nullptr;
+    return slot;
+  }
   unsigned image_width_, image_height_;
   precision_t scale_factor_, log_scale_factor_;
   unsigned init_threshold_FAST_, min_threshold_FAST_;

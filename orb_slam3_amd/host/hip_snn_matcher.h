@@ -1,7 +1,8 @@
 // GPU-backed bodies for the reference's matcher entry points.
 //
-// SNNMatcher<It>::MatchWithIterators (src/features/matching/second_nearest_neighbor_matcher.hpp:30-80) is a
-// header-only template, not a virtual seam, so the replacement keeps the call shape of its three users and gathers
+// The workhorse behind the same-name replacements in features/ (second_nearest_neighbor_matcher.hpp,
+// validators/orientation_validator.h): SNNMatcher<It>::MatchWithIterators
+// (src/features/matching/second_nearest_neighbor_matcher.hpp:30-80) per candidate generator, each gathering
 // (descriptor, position, radius, level-range) arrays for ONE batched C-ABI call:
 //   * MatchArea       <- SNNMatcher<AreaToIterator>          (frame/monocular/monocular_frame.cpp:173-184)
 //   * MatchProjection <- SNNMatcher<ProjectionSearchIterator> (monocular_frame.cpp:285-306, monocular_key_frame.cpp:183-216,353-376)
@@ -12,6 +13,7 @@
 #define ORB_SLAM3_AMD_HIP_SNN_MATCHER_H_
 
 #include <algorithm>
+#include <iterator>
 #include <list>
 #include <map>
 #include <stdexcept>
@@ -33,11 +35,14 @@ class HipSNNMatcher {
   HipSNNMatcher(orbgpu_ctx * ctx, precision_t nearest_neighbour_ratio, unsigned threshold)
       : ctx_(ctx), nearest_neighbour_ratio_(nearest_neighbour_ratio), THRESHOLD_(threshold) {}
 
-  // AreaToIterator(0 .. Size(), to, from, window_size): level-0 window search on both sides; id 0 is visited
-  // whatever its level (iterators/area_to_iterator.h:24-43, area_to_pointee.h:43-54)
+  // AreaToIterator(begin_id .. end_id, to, from, window_size): level-0 window search on both sides; the first id is
+  // visited whatever its level, the following ones only when they are level-0 keypoints
+  // (iterators/area_to_iterator.h:24-43, area_to_pointee.h:43-54).  The reference calls it with 0 .. Size().
   void MatchArea(const Features & to, const Features & from, size_t window_size,
-                 std::unordered_map<std::size_t, std::size_t> & out_matches) const {
+                 std::unordered_map<std::size_t, std::size_t> & out_matches, size_t begin_id = 0,
+                 size_t end_id = (size_t)-1) const {
     const size_t nt = to.Size(), nf = from.Size();
+    end_id = std::min(end_id, nt);
     std::vector<double> to_xy(2 * nt), from_xy(2 * nf);
     std::vector<uint64_t> win(nt, (uint64_t)window_size);
     std::vector<int32_t> lmin(nt, 0), lmax(nt, 0), flev(nf);
@@ -45,7 +50,7 @@ class HipSNNMatcher {
     for (size_t i = 0; i < nt; ++i) {
       to_xy[2 * i] = to.keypoints[i].X();
       to_xy[2 * i + 1] = to.keypoints[i].Y();
-      active[i] = (i == 0) || (to.keypoints[i].level == 0);
+      active[i] = i >= begin_id && i < end_id && (i == begin_id || to.keypoints[i].level == 0);
     }
     Fill(from, from_xy, flev);
     Run(to.descriptors.data(), nt, to_xy, win, lmin, lmax, &active, from, from_xy, flev,
@@ -57,14 +62,20 @@ class HipSNNMatcher {
   // ListFeaturesInArea (features.cpp:82); levels [max(l-1,0), l+1]
   void MatchProjection(const std::list<frame::MapPointVisibilityParams> & visibles, const Features & from,
                        std::unordered_map<map::MapPoint *, std::size_t> & out_matches) const {
-    const size_t nt = visibles.size(), nf = from.Size();
+    MatchProjection(visibles.begin(), visibles.end(), from, out_matches);
+  }
+  void MatchProjection(std::list<frame::MapPointVisibilityParams>::const_iterator vis_begin,
+                       std::list<frame::MapPointVisibilityParams>::const_iterator vis_end, const Features & from,
+                       std::unordered_map<map::MapPoint *, std::size_t> & out_matches) const {
+    const size_t nt = (size_t)std::distance(vis_begin, vis_end), nf = from.Size();
     std::vector<uint8_t> to_desc(32 * nt);
     std::vector<double> to_xy(2 * nt), from_xy(2 * nf);
     std::vector<uint64_t> win(nt);
     std::vector<int32_t> lmin(nt), lmax(nt), flev(nf);
     std::vector<map::MapPoint *> ids(nt);
     size_t i = 0;
-    for (const auto & v : visibles) {
+    for (auto vit = vis_begin; vit != vis_end; ++vit) {
+      const frame::MapPointVisibilityParams & v = *vit;
       const DescriptorType d = v.map_point->GetDescriptor();
       std::copy(d.data(), d.data() + 32, to_desc.begin() + 32 * i);
       to_xy[2 * i] = v.position.x();
@@ -86,13 +97,20 @@ class HipSNNMatcher {
   template <class FeatureVector>
   void MatchBow(const FeatureVector & feature_vector_to, const FeatureVector & feature_vector_from, const Features & to,
                 const Features & from, std::unordered_map<std::size_t, std::size_t> & out_matches) const {
+    MatchBow(feature_vector_to, feature_vector_from, to, from, out_matches, feature_vector_to.begin(), feature_vector_to.end());
+  }
+  // the nodes [to_first, to_last) of feature_vector_to (BowToIterator begin / end, dbo_w2_handler.cpp:53-63)
+  template <class FeatureVector>
+  void MatchBow(const FeatureVector & feature_vector_to, const FeatureVector & feature_vector_from, const Features & to,
+                const Features & from, std::unordered_map<std::size_t, std::size_t> & out_matches,
+                typename FeatureVector::const_iterator to_first, typename FeatureVector::const_iterator to_last) const {
     const size_t nt = to.Size(), nf = from.Size();
     if (nt == 0) return;
     std::vector<int32_t> to_off{0}, from_off{0};
     std::vector<uint32_t> to_ids, from_ids;
-    auto it_to = feature_vector_to.begin();
+    auto it_to = to_first;
     auto it_from = feature_vector_from.begin();
-    while (it_to != feature_vector_to.end() && it_from != feature_vector_from.end()) {
+    while (it_to != to_last && it_to != feature_vector_to.end() && it_from != feature_vector_from.end()) {
       if (it_to->first == it_from->first) {
         to_ids.insert(to_ids.end(), it_to->second.begin(), it_to->second.end());
         from_ids.insert(from_ids.end(), it_from->second.begin(), it_from->second.end());
