@@ -243,11 +243,33 @@ float oo_ic_angle(const uint8_t *img, int stride, int cx, int cy) {
   return oo_fast_atan2((float)m_01, (float)m_10);
 }
 
-/* computeOrbDescriptor, :120-165 (float details SURVEY App. B.5) */
-void oo_orb_descriptor(const uint8_t *img, int stride, int cx, int cy, double angle_deg, uint8_t *desc) {
+/* cos / sin of the keypoint angle, :124-125: `(float) cos(angle)` on a float.  Which function that names depends on the
+ * headers in scope: ::cos(double) (plain <cmath>; the float is widened, the correctly rounded double result rounded to
+ * float: variant 0, the default here and in the kernel) or the float overload = cosf (<math.h> in scope; glibc's cosf
+ * is within 1 ulp but not always the rounded value: variant 1).  Build with -DOO_TRIG_COSF=1 to make variant 1 the
+ * default; oo_set_trig_variant switches at run time (tests/test_oracle.py reports how far the two are apart). */
+#ifndef OO_TRIG_COSF
+#define OO_TRIG_COSF 0
+#endif
+static int g_trig_variant = OO_TRIG_COSF;
+void oo_set_trig_variant(int v) { g_trig_variant = v ? 1 : 0; }
+int oo_get_trig_variant(void) { return g_trig_variant; }
+void oo_descriptor_trig(double angle_deg, int variant, float *cos_out, float *sin_out) {
   const double factorPI = (M_PI / 180.); /* :11 */
   float angle = (float)((float)angle_deg * factorPI);
-  float a = (float)cos((double)angle), b = (float)sin((double)angle);
+  if (variant) {
+    *cos_out = cosf(angle);
+    *sin_out = sinf(angle);
+  } else {
+    *cos_out = (float)cos((double)angle);
+    *sin_out = (float)sin((double)angle);
+  }
+}
+
+/* computeOrbDescriptor, :120-165 (float details SURVEY App. B.5) */
+void oo_orb_descriptor(const uint8_t *img, int stride, int cx, int cy, double angle_deg, uint8_t *desc) {
+  float a, b;
+  oo_descriptor_trig(angle_deg, g_trig_variant, &a, &b);
   const uint8_t *center = img + (ptrdiff_t)cy * stride + cx;
   const int8_t *pat = k_pattern;
   for (int i = 0; i < 32; ++i) {

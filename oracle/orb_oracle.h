@@ -77,6 +77,10 @@ float oo_fast_atan2(float y, float x);
 float oo_ic_angle(const uint8_t *img, int stride, int cx, int cy);
 /* computeOrbDescriptor :120-165; angle_deg is kpt.angle */
 void oo_orb_descriptor(const uint8_t *blurred, int stride, int cx, int cy, double angle_deg, uint8_t *desc32);
+/* cos / sin variant of the descriptor rotation: 0 = cos(double) rounded to float (default), 1 = cosf / sinf of the host libm */
+void oo_set_trig_variant(int variant);
+int oo_get_trig_variant(void);
+void oo_descriptor_trig(double angle_deg, int variant, float *cos_out, float *sin_out);
 /* closed-form FAST-9/16 score  max(M_dark, M_bright) - 1  (App. A.2); may be <= 0 */
 int oo_fast_score(const uint8_t *img, int stride, int x, int y);
 /* threshold-independent score map: S = score if score >= min_thr else 0, zero outside [3,w-4]x[3,h-4] */

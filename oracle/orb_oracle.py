@@ -116,6 +116,17 @@ def orb_descriptor(blurred, cx, cy, angle_deg):
     return d
 
 
+def set_trig_variant(variant):
+    """0: (float)cos((double)a) (default), 1: cosf(a) of the host libm -- see oo_descriptor_trig."""
+    lib().oo_set_trig_variant(int(variant))
+
+
+def descriptor_trig(angle_deg, variant):
+    c, s = C.c_float(0), C.c_float(0)
+    lib().oo_descriptor_trig(C.c_double(float(angle_deg)), int(variant), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
 def fast_score_map(img, min_thr=7):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     out = np.empty_like(img)

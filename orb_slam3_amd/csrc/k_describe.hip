@@ -211,10 +211,17 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
   if (threadIdx.x < KPG) {
     const double factorPI = 3.14159265358979323846 / 180.;
     const float ang = (float)((double)s_angle[threadIdx.x] * factorPI);
+#ifdef ORBGPU_TRIG_F32
+    // build-time variant (make TRIG=f32): the float overloads, as a reference build that has <math.h> in scope would
+    // call.  The device's cosf / sinf are not glibc's bit for bit: this switch measures sensitivity, it claims no parity
+    s_cs[threadIdx.x][0] = cosf(ang);
+    s_cs[threadIdx.x][1] = sinf(ang);
+#else
     double sn, cs;
     sincos((double)ang, &sn, &cs);  // one shared range reduction; same kernels as sin() / cos()
     s_cs[threadIdx.x][0] = (float)cs;
     s_cs[threadIdx.x][1] = (float)sn;
+#endif
   }
   __syncthreads();
   const int total = s_prefix[ORBGPU_MAX_LEVELS - 1];
