@@ -612,7 +612,9 @@ __global__ __launch_bounds__(NT) void k_quadtree(DeviceGeom g, QtArgs a) {
   __shared__ u64 wsum[(NT / 64)];
   __shared__ int s_misc[8];
   STAMP(0);
-  const int l = blockIdx.x, f = blockIdx.y;
+  // workgroups are handed out in blockIdx.x-fastest order: every frame of level 0 first, then level 1, ... -- the
+  // longest jobs (the levels with the most candidates) start first and the short ones fill in behind them
+  const int f = blockIdx.x, l = blockIdx.y;
   const LevelGeom L = g.lv[l];
   const int cap = a.node_cap;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -721,7 +723,7 @@ int launch_quadtree(const orbgpu_ctx *c, FrameSlice fs, const int *budget) {
   a.prof = nullptr;
   const bool profile = getenv("ORBGPU_QT_PROFILE") != nullptr;
   if (profile && hipMalloc(&a.prof, 64 * 8) == hipSuccess) (void)hipMemset(a.prof, 0, 64 * 8);
-  const dim3 grid(g.levels, n_frames);
+  const dim3 grid(n_frames, g.levels);
   if (nodes_global) {
     if (big) hipLaunchKernelGGL((k_quadtree<1024, true>), grid, dim3(1024), lds, fs.stream, g, a);
     else hipLaunchKernelGGL((k_quadtree<256, true>), grid, dim3(256), lds, fs.stream, g, a);
