@@ -200,6 +200,23 @@ int orbgpu_match_window(orbgpu_ctx *ctx, const orbgpu_window_args *args, int32_t
 int orbgpu_match_window_device(orbgpu_ctx *ctx, const orbgpu_window_args *device_args, int32_t *d_from_idx_per_to,
                                uint32_t *d_dist);
 
+/* replaces: many SNNMatcher<ProjectionSearchIterator>::MatchWithIterators calls (one per frame: MonocularFrame::
+ * SearchInVisiblePoints, frame/monocular/monocular_frame.cpp:285-306; MonocularKeyFrame::MatchVisibleMapPoints,
+ * monocular_key_frame.cpp:183-216) in ONE launch, for offline batches: *device_args holds the arrays of all searches
+ * back to back (device pointers; n_to / n_from = total rows), and segment s searches the 'to' rows
+ * [to_begin, to_begin + to_count) among the 'from' rows [from_begin, from_begin + from_count) only -- same candidate
+ * rule, threshold, ratio and per-'from' uniqueness as orbgpu_match_window, independently per segment.
+ * d_from_idx_per_to[i] is the 'from' index RELATIVE to the segment's from_begin, or -1.  'to' rows outside every
+ * segment are not written.  Segments must not overlap in 'to' rows; 'from' ranges may be shared only by segments
+ * whose uniqueness is meant to be shared.  max_to_count = the largest to_count (the host knows it from building the
+ * segments); d_segments has n_segments entries.  Asynchronous on the context's stream. */
+typedef struct {
+  int32_t to_begin, to_count, from_begin, from_count;
+} orbgpu_segment;
+int orbgpu_match_window_segments_device(orbgpu_ctx *ctx, const orbgpu_window_args *device_args,
+                                        const orbgpu_segment *d_segments, int32_t n_segments, int32_t max_to_count,
+                                        int32_t *d_from_idx_per_to, uint32_t *d_dist);
+
 /* replaces: the matcher inside DBoW2Handler::FastMatch (features/handlers/DBoW2/dbo_w2_handler.cpp:25-72):
  * SNNMatcher<BowToIterator>, candidates restricted to features of the same vocabulary node
  * (handlers/DBoW2/bow_to_iterator.cpp:12-47, bow_to_pointee.h:37-45).  The caller joins the two

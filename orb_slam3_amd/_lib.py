@@ -60,6 +60,7 @@ class BowScoreArgs(C.Structure):
                 ("kf_counts", C.c_void_p), ("scoring", C.c_int32), ("reserved", C.c_int32)]
 
 
+SEGMENT_DTYPE = np.dtype([("to_begin", "<i4"), ("to_count", "<i4"), ("from_begin", "<i4"), ("from_count", "<i4")])
 KP_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("angle", "<f4"), ("size", "<i4"), ("level", "<i4"), ("reserved", "<i4")])
 assert KP_DTYPE.itemsize == 32
 
@@ -68,7 +69,7 @@ EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_g
            "orbgpu_synchronize", "orbgpu_set_stream", "orbgpu_set_batch_slices", "orbgpu_wait_event", "orbgpu_record_event", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
            "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_bruteforce_noalloc_device",
            "orbgpu_match_window",
-           "orbgpu_match_window_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
+           "orbgpu_match_window_device", "orbgpu_match_window_segments_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
            "orbgpu_match_allpairs_device", "orbgpu_vocab_create", "orbgpu_vocab_destroy", "orbgpu_bow_transform",
            "orbgpu_bow_transform_device", "orbgpu_distinctive_descriptor", "orbgpu_distinctive_descriptor_device",
            "orbgpu_keypoint_geometry", "orbgpu_keypoint_geometry_device", "orbgpu_bow_score", "orbgpu_bow_score_device",
@@ -110,6 +111,7 @@ def load():
         "orbgpu_match_bruteforce_noalloc_device": (i32, [vp, vp, i32, vp, i32, u32, dbl, vp, vp]),
         "orbgpu_match_window": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_window_device": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
+        "orbgpu_match_window_segments_device": (i32, [vp, C.POINTER(WindowArgs), vp, i32, i32, vp, vp]),
         "orbgpu_match_frames_device": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, u64, u32, dbl, i32, vp, vp, vp]),
         "orbgpu_match_groups": (i32, [vp, C.POINTER(GroupArgs), vp, vp]),
         "orbgpu_match_groups_device": (i32, [vp, C.POINTER(GroupArgs), i32, vp, vp]),

@@ -795,6 +795,30 @@ int orbgpu_match_window_device(orbgpu_ctx *ctx, const orbgpu_window_args *a, int
 }
 
 
+int orbgpu_match_window_segments_device(orbgpu_ctx *ctx, const orbgpu_window_args *a, const orbgpu_segment *d_segments,
+                                        int32_t n_segments, int32_t max_to_count, int32_t *d_from_idx_per_to,
+                                        uint32_t *d_dist) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (n_segments < 0 || max_to_count < 0 || a->n_to < 0 || a->n_from < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (n_segments == 0 || max_to_count == 0) return ORBGPU_OK;
+  if (!d_segments || !a->to_desc || !a->to_xy || !a->to_window || !a->to_min_level || !a->to_max_level || !d_from_idx_per_to ||
+      !d_dist)
+    return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_from > 0 && (!a->from_desc || !a->from_xy || !a->from_level)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_from >= (1 << 23)) return fail(ctx, ORBGPU_E_INVALID, "a segment's from_count must be below 2^23");
+  if (!(a->ratio >= 0.0)) return fail(ctx, ORBGPU_E_INVALID, "ratio must be >= 0");
+  if (n_segments > 65535) return fail(ctx, ORBGPU_E_INVALID, "more than 65535 segments in one call");
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = ensure_match_scratch(ctx, (size_t)std::max(a->n_from, 1) * sizeof(unsigned long long) + 256);
+  if (rc) return rc;
+  launch_match_segments(ctx, *a, d_segments, n_segments, max_to_count, a->n_from, d_from_idx_per_to,
+                        reinterpret_cast<unsigned *>(d_dist), ctx->d_match_scratch);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
 int orbgpu_match_window(orbgpu_ctx *ctx, const orbgpu_window_args *a, int32_t *from_idx_per_to, uint32_t *dist) {
   if (!ctx) return ORBGPU_E_INVALID;
   std::lock_guard<std::mutex> lock(ctx->mu);

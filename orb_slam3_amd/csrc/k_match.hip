@@ -197,6 +197,65 @@ __global__ __launch_bounds__(256) void k_snn_resolve(int n_to, int *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Many independent window searches in one launch (search by projection over a batch of frames: one
+// SNNMatcher<ProjectionSearchIterator>::MatchWithIterators per segment, monocular_frame.cpp:285-306).  Segment s pairs
+// the 'to' rows [to_begin, to_begin + to_count) with the 'from' rows [from_begin, from_begin + from_count) of the
+// concatenated arrays.  grid: x = 256-row 'to' blocks of a segment, y = segment.  A segment's 'from' rows are few
+// (one frame's keypoints), so a lane scans all of them -- wave-uniform scalar loads, window / level predicate before
+// the distance -- and applies threshold and ratio itself; claims are keyed by the global 'from' row.
+__global__ __launch_bounds__(256) void k_snn_segments(orbgpu_window_args a, const orbgpu_segment *__restrict__ segs,
+                                                      int *__restrict__ from_idx, unsigned *__restrict__ dist,
+                                                      unsigned long long *__restrict__ claim) {
+  const orbgpu_segment sg = segs[blockIdx.y];
+  if ((int)(blockIdx.x * 256) >= sg.to_count) return;
+  const int li = blockIdx.x * 256 + threadIdx.x;
+  const bool live = li < sg.to_count;
+  const int i = sg.to_begin + min(li, sg.to_count - 1);
+  const uint4 *td = reinterpret_cast<const uint4 *>(a.to_desc) + 2 * (size_t)i;
+  const uint4 t0 = td[0], t1 = td[1];
+  const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  ToWindow tw;
+  tw.x = a.to_xy[2 * (size_t)i];
+  tw.y = a.to_xy[2 * (size_t)i + 1];
+  tw.win = (double)a.to_window[i];
+  tw.lmin = a.to_min_level[i];
+  tw.lmax = a.to_max_level[i];
+  tw.check_levels = (tw.lmin > 0) || (tw.lmax >= 0);  // features.cpp:94
+  const uint4 *__restrict__ fd = reinterpret_cast<const uint4 *>(a.from_desc) + 2 * (size_t)sg.from_begin;
+  const double2 *__restrict__ fxy = reinterpret_cast<const double2 *>(a.from_xy) + sg.from_begin;
+  const int *__restrict__ flv = a.from_level + sg.from_begin;
+  unsigned best = KEY_NONE, second = KEY_NONE;
+#pragma unroll 2
+  for (int j = 0; j < sg.from_count; j++) {
+    const bool ok = live && window_ok(tw, fxy[j], flv[j]);
+    if (!__ballot(ok)) continue;  // no lane of the wave has this candidate in its window
+    unsigned key = (hamming8(t, fd[2 * j], fd[2 * j + 1]) << IDX_BITS) | (unsigned)j;
+    key = ok ? key : KEY_NONE;
+    second = umed3(best, key, second);
+    best = min(best, key);
+  }
+  if (!live) return;
+  unsigned d = 0;
+  int j = snn_accept(best, second, a.threshold, a.ratio, d);
+  if (a.to_active && !a.to_active[i]) j = -1;
+  from_idx[i] = j;
+  dist[i] = d;
+  if (j >= 0) atomicMin(&claim[sg.from_begin + j], ((unsigned long long)d << 32) | (unsigned)li);
+}
+
+__global__ __launch_bounds__(256) void k_snn_segments_resolve(const orbgpu_segment *__restrict__ segs,
+                                                              int *__restrict__ from_idx,
+                                                              const unsigned *__restrict__ dist,
+                                                              const unsigned long long *__restrict__ claim) {
+  const orbgpu_segment sg = segs[blockIdx.y];
+  const int li = blockIdx.x * 256 + threadIdx.x;
+  if (li >= sg.to_count) return;
+  const int i = sg.to_begin + li;
+  const int j = from_idx[i];
+  if (j >= 0 && claim[sg.from_begin + j] != (((unsigned long long)dist[i] << 32) | (unsigned)li)) from_idx[i] = -1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Rotation histogram (orientation_validator.cpp:16-97) for one match list, executed by one workgroup.
 // angle getters return the float the extractor produced (the reference stores it in a double).
 template <class AngTo, class AngFrom>
@@ -904,6 +963,18 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
                      capacity, d_to_frame, d_from_frame, n_chunks, partial, th, ratio, d_match, d_dist, claim);
   hipLaunchKernelGGL(k_link_resolve, dim3(n_pairs), dim3(256), 0, c->stream, d_kp, d_n, capacity, d_to_frame,
                      d_from_frame, claim, check_orientation, d_match, d_dist, d_n_matches);
+}
+
+// claim: one u64 per 'from' row of the concatenated arrays (scratch holds n_from_total of them)
+void launch_match_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, const orbgpu_segment *d_segs, int n_segments,
+                           int max_to_count, int n_from_total, int *d_from_idx, unsigned *d_dist, void *scratch) {
+  unsigned long long *claim = reinterpret_cast<unsigned long long *>(scratch);
+  (void)hipMemsetAsync(claim, 0xff, (size_t)n_from_total * sizeof(unsigned long long), c->stream);
+  orbgpu_window_args b = a;
+  b.threshold = std::min(a.threshold, 256u);
+  const dim3 grid((max_to_count + 255) / 256, n_segments);
+  hipLaunchKernelGGL(k_snn_segments, grid, dim3(256), 0, c->stream, b, d_segs, d_from_idx, d_dist, claim);
+  hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim);
 }
 
 size_t group_scratch_bytes(int n_from, int n_slots) { return (size_t)n_from * 8 + (size_t)n_slots * 8 + 256; }

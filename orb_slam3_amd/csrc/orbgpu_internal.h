@@ -208,6 +208,8 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
                          int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
                          unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,
                          int *d_n_matches);
+void launch_match_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, const orbgpu_segment *d_segs, int n_segments,
+                           int max_to_count, int n_from_total, int *d_from_idx, unsigned *d_dist, void *scratch);
 size_t group_scratch_bytes(int n_from, int n_slots);
 void launch_match_groups(const orbgpu_ctx *c, const orbgpu_group_args &a, int n_slots, int *d_from_idx, unsigned *d_dist,
                          void *scratch);

@@ -282,3 +282,67 @@ def test_keypoint_geometry_parity(oracle, fe):
         MonocularCamera(500, 500, 320, 240, 1, (0,) * 8).UndistortFeatures(fe, f)     # BARREL8
     f0 = Features(640, 480)
     assert len(MonocularCamera(500, 500, 320, 240).UndistortFeatures(fe, f0)) == 0
+
+
+def test_window_segments_parity(oracle, fe):
+    """orbgpu_match_window_segments_device: many independent search-by-projection problems in one launch, ragged and
+    empty segments included, padded layout (gaps between segments), against one oracle call per segment."""
+    import ctypes as C
+    import torch
+    from orb_slam3_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    sizes = [(300, 280), (0, 50), (1, 1), (700, 0), (513, 900), (256, 257), (40, 1500)]
+    cap_to, cap_from = 720, 1600                      # padded slots: segment s owns rows [s * cap, s * cap + count)
+    S = len(sizes)
+    to_desc = rng.integers(0, 256, (S * cap_to, 32), dtype=np.uint8)
+    from_desc = rng.integers(0, 256, (S * cap_from, 32), dtype=np.uint8)
+    to_xy = rng.uniform(0, 640, (S * cap_to, 2))
+    from_xy = rng.uniform(0, 640, (S * cap_from, 2))
+    to_lv = rng.integers(0, 8, S * cap_to).astype(np.int32)
+    from_lv = rng.integers(0, 8, S * cap_from).astype(np.int32)
+    win = (np.float64(24.0) * np.float64(1.2) ** to_lv).astype(np.uint64)        # truncated radius
+    segs = np.zeros(S, _lib.SEGMENT_DTYPE)
+    for s, (nt, nf) in enumerate(sizes):
+        segs[s] = (s * cap_to, nt, s * cap_from, nf)
+        k = min(nt, nf)
+        if k:                                         # planted matches: a 'to' near a 'from' with a close descriptor
+            j = rng.choice(nf, k, replace=False)
+            i = rng.choice(nt, k, replace=False)
+            to_desc[s * cap_to + i] = from_desc[s * cap_from + j]
+            to_desc[s * cap_to + i, :2] ^= rng.integers(0, 256, (k, 2)).astype(np.uint8)
+            to_xy[s * cap_to + i] = from_xy[s * cap_from + j] + rng.uniform(-5, 5, (k, 2))
+            to_lv[s * cap_to + i] = np.clip(from_lv[s * cap_from + j] + rng.integers(-1, 2, k), 0, 7)
+            if k > 8:                                 # contested claim and a best == second tie
+                to_desc[s * cap_to + i[1]] = to_desc[s * cap_to + i[0]]
+                to_xy[s * cap_to + i[1]] = to_xy[s * cap_to + i[0]]
+                to_lv[s * cap_to + i[1]] = to_lv[s * cap_to + i[0]]
+    win = (np.float64(24.0) * np.float64(1.2) ** to_lv).astype(np.uint64)
+    lmin, lmax = np.maximum(to_lv - 1, 0).astype(np.int32), (to_lv + 1).astype(np.int32)
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in dict(
+        to_desc=to_desc, from_desc=from_desc, to_xy=to_xy, from_xy=from_xy, win=win.view(np.int64), lmin=lmin, lmax=lmax,
+        from_lv=from_lv, segs=segs.view(np.int32).reshape(S, 4)).items()}
+    d_idx = torch.full((S * cap_to,), 777, dtype=torch.int32, device=dev)
+    d_dist = torch.full((S * cap_to,), 777, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for th, ratio in ((100, 0.9), (100, 0.8), (50, 1.0)):
+        a = _lib.WindowArgs(t["to_desc"].data_ptr(), t["to_xy"].data_ptr(), t["win"].data_ptr(), t["lmin"].data_ptr(),
+                            t["lmax"].data_ptr(), None, S * cap_to, t["from_desc"].data_ptr(), t["from_xy"].data_ptr(),
+                            t["from_lv"].data_ptr(), S * cap_from, th, ratio)
+        rc = lib.orbgpu_match_window_segments_device(fe.handle, C.byref(a), t["segs"].data_ptr(), S,
+                                                     max(nt for nt, _ in sizes), d_idx.data_ptr(), d_dist.data_ptr())
+        assert rc == 0, lib.orbgpu_last_error(fe.handle)
+        assert lib.orbgpu_synchronize(fe.handle) == 0
+        gi, gd = d_idx.cpu().numpy(), d_dist.cpu().numpy().view(np.uint32)
+        total = 0
+        for s, (nt, nf) in enumerate(sizes):
+            ts, fs = slice(s * cap_to, s * cap_to + nt), slice(s * cap_from, s * cap_from + nf)
+            omf, omd = oracle.snn_match(to_desc[ts], from_desc[fs], th, ratio, to_xy=to_xy[ts], to_window=win[ts],
+                                        to_min_level=lmin[ts], to_max_level=lmax[ts], from_xy=from_xy[fs], from_level=from_lv[fs])
+            assert np.array_equal(gi[ts], omf), (s, th, ratio)
+            sel = omf >= 0
+            assert np.array_equal(gd[ts][sel], omd[sel])
+            assert (gi[s * cap_to + nt:(s + 1) * cap_to] == 777).all()       # rows outside the segment are not written
+            total += int(sel.sum())
+        assert total > 300
