@@ -75,7 +75,7 @@ EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_g
            "orbgpu_keypoint_geometry", "orbgpu_keypoint_geometry_device", "orbgpu_bow_score", "orbgpu_bow_score_device",
            "orbgpu_bowdb_create", "orbgpu_bowdb_destroy", "orbgpu_bowdb_append", "orbgpu_bowdb_erase", "orbgpu_bowdb_size",
            "orbgpu_bowdb_query",
-           "orbgpu_rotation_filter", "orbgpu_stage_times",
+           "orbgpu_rotation_filter", "orbgpu_stage_times", "orbgpu_set_stage_timing",
            "orbgpu_popcount_peak"]
 
 _lib = None
@@ -134,6 +134,7 @@ def load():
         "orbgpu_bowdb_query": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, C.POINTER(i32)]),
         "orbgpu_rotation_filter": (i32, [vp, vp, i32, vp, i32, vp, C.POINTER(i32)]),
         "orbgpu_stage_times": (i32, [vp, vp]),
+        "orbgpu_set_stage_timing": (i32, [vp, i32]),
         "orbgpu_popcount_peak": (i32, [vp, C.POINTER(dbl)]),
     }
     for name, (res, args) in sig.items():

@@ -226,15 +226,13 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     const FrameSlice fs{f0, f1 - f0, s == 0 ? ctx->stream : ctx->slice_stream[s]};
     const FrameSlice fb{f0, f1 - f0, ctx->slice_blur[s]};
     hipEvent_t *sev = ctx->slice_ev[s];
-    const bool timed = s == 0;  // the stage timers follow slice 0
+    const bool timed = s == 0 && ctx->stage_timing;  // the stage timers follow slice 0
+    const bool timed_fast = s == 0;                  // the FAST kernel (the roofline kernel) is always bracketed
     if (s > 0) HIP_TRY(hipStreamWaitEvent(fs.stream, ev[0], 0));  // fork: after everything already on the context's stream
     for (int l = 1; l < L; l++) launch_pyramid_level(ctx, fs, l);
-    if (timed) HIP_TRY(hipEventRecord(ev[1], fs.stream));
+    if (timed_fast) HIP_TRY(hipEventRecord(ev[1], fs.stream));
     launch_fast_cells(ctx, fs, nullptr);
-    if (timed) {
-      HIP_TRY(hipEventRecord(ev[2], fs.stream));
-      HIP_TRY(hipEventRecord(ev[3], fs.stream));
-    }
+    if (timed_fast) HIP_TRY(hipEventRecord(ev[2], fs.stream));
     HIP_TRY(hipEventRecord(sev[0], fs.stream));
     // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
     // dependent rounds in levels x frames workgroups and leaves most of the chip idle
@@ -259,6 +257,7 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   HIP_TRY(hipEventRecord(ev[9], ctx->stream));  // every slice has finished
   HIP_TRY(hipMemcpyAsync(ctx->h_error_flag, ctx->d_error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipGetLastError());
+  ctx->ev_full[ctx->ev_head] = ctx->stage_timing;
   ctx->ev_head = (ctx->ev_head + 1) % ORBGPU_EV_SETS;
   ctx->ev_pending = std::min(ctx->ev_pending + 1, ORBGPU_EV_SETS);
   ctx->last_frames = n_frames;
@@ -277,9 +276,13 @@ int finish_pipeline(orbgpu_ctx *ctx) {
     float acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int k = 1; k <= n; k++) {
       hipEvent_t *ev = ctx->ev[(ctx->ev_head - k + ORBGPU_EV_SETS) % ORBGPU_EV_SETS];
-      for (int i = 0; i < 4; i++) acc[i] += elapsed(ev[i], ev[i + 1]);
-      acc[4] += elapsed(ev[7], ev[8]);  // blur, on its own stream (overlaps the quadtree stage)
-      acc[5] += elapsed(ev[5], ev[6]);
+      acc[0] += elapsed(ev[0], ev[1]);
+      acc[1] += elapsed(ev[1], ev[2]);  // FAST score + cells; [2] (cells) has no kernel of its own any more
+      if (ctx->ev_full[(ctx->ev_head - k + ORBGPU_EV_SETS) % ORBGPU_EV_SETS]) {
+        acc[3] += elapsed(ev[2], ev[4]);
+        acc[4] += elapsed(ev[7], ev[8]);  // blur, on its own stream (overlaps the quadtree stage)
+        acc[5] += elapsed(ev[5], ev[6]);
+      }
       acc[6] += elapsed(ev[0], ev[9]);
     }
     for (int i = 0; i < 7; i++) ctx->stage_ms[i] = acc[i] / (float)n;
@@ -346,6 +349,8 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   {
     const char *z = std::getenv("ORBGPU_NO_ZERO_COPY");
     ctx->no_zero_copy = z && z[0] == '1';
+    const char *lt = std::getenv("ORBGPU_STAGE_TIMING");  // 1: start with every stage boundary timed
+    ctx->stage_timing = lt && lt[0] == '1';
     const char *o = std::getenv("ORBGPU_SLICES");  // tuning aid: slices per batch, 0 / unset = automatic
     ctx->n_slices = o ? std::atoi(o) : 0;
   }
@@ -492,6 +497,13 @@ int orbgpu_set_stream(orbgpu_ctx *ctx, void *stream) {
   int rc = finish_pipeline(ctx);
   ctx->stream = stream ? static_cast<hipStream_t>(stream) : ctx->own_stream;
   return rc;
+}
+
+int orbgpu_set_stage_timing(orbgpu_ctx *ctx, int32_t all_stages) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  ctx->stage_timing = all_stages != 0;
+  return ORBGPU_OK;
 }
 
 int orbgpu_set_batch_slices(orbgpu_ctx *ctx, int32_t n_slices) {

@@ -146,6 +146,8 @@ struct orbgpu_ctx {
   hipEvent_t ev[ORBGPU_EV_SETS][10]{};  // stage boundaries of the last ORBGPU_EV_SETS extract calls (ring);
                                        // [7], [8] bracket the blur on its own stream, [9] = all slices joined
   int ev_head = 0, ev_pending = 0;
+  bool ev_full[ORBGPU_EV_SETS]{};      // that set holds every stage boundary, not only the FAST kernel's and the total
+  bool stage_timing = false;           // record every stage boundary (each event costs a few microseconds between kernels)
   float stage_ms[7]{};
   int last_frames = 0;
   int last_feature_count = 0;

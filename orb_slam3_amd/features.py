@@ -178,6 +178,9 @@ class ORBFeatureExtractor:
         return {"pyramid": pyr, "score": score, "blurred": blur, "cand_x": cx[:n], "cand_y": cy[:n],
                 "cand_score": cs[:n], "n_cands": ncl[:g.levels].tolist(), "geometry": g}
 
+    def set_stage_timing(self, all_stages):
+        self._check(self._lib.orbgpu_set_stage_timing(self._h, 1 if all_stages else 0))
+
     def stage_times(self):
         ms = np.zeros(7, np.float32)
         self._check(self._lib.orbgpu_stage_times(self._h, _lib.ptr(ms)))
