@@ -47,8 +47,8 @@ def launch_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -243,17 +243,19 @@ def main():
     fast_gbs = P * B / fast_s / 1e9 if fast_s > 0 else 0.0
     # HBM-side bytes per launch from the committed counter passes (tools/profile_round.sh -> profiles/): valid for the
     # default workload only, null otherwise
-    traffic, traffic_src = None, None
-    tfile = ROOT / "profiles" / "r1_hbm_traffic.json"
+    traffic, traffic_src, sq = None, None, {}
+    tfile = ROOT / "profiles" / "r2_hbm_traffic.json"
     if tfile.exists() and headline:
         tj = json.loads(tfile.read_text())
-        traffic = tj["kernels"].get("k_fast_score", {}).get("hbm_bytes")
-        traffic_src = "profiles/r1_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this workload)"
-    roofline = {"bound": "hbm", "kernel": "k_fast_score", "achieved": round(fast_gbs, 2), "peak": hbm_peak,
+        traffic = tj["kernels"].get("k_fast_cells", {}).get("hbm_bytes")
+        traffic_src = "profiles/r2_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this workload)"
+        sq = tj.get("sq_counters_per_launch", {})
+    roofline = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": round(fast_gbs, 2), "peak": hbm_peak,
                 "unit": "GB/s", "frac": round(fast_gbs / hbm_peak, 5), "traffic": traffic,
                 "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P * B, "traffic_source": traffic_src,
-                "limiter": "vector-ALU issue, not HBM: ~2.8e3 VALU wave-instructions per 128x32 tile at ~0.9 per clock per CU "
-                           "(profiles/r1_pmc_sq.txt, profiles/r1_valu_rate.txt)"}
+                "limiter": "instruction issue, not HBM: the kernel (FAST score + per-cell NMS, fallback and compaction, fused) "
+                           "issues about one vector instruction per clock per CU, the measured ceiling of its mix "
+                           "(profiles/r2_hbm_traffic.json sq_counters_per_launch, profiles/r1_valu_rate.txt)"}
     # whole extraction against SURVEY 8d's per-frame figure A = 5P - px0 - px7 + 1978 N
     A = 5 * P - g.w[0] * g.h[0] - g.w[g.levels - 1] * g.h[g.levels - 1] + 1978 * NF
     ext_s = st[6] * 1e-3
@@ -275,6 +277,21 @@ def main():
         k: round(stage_bytes[k] * B / (pipeline["stage_ms"][k] * 1e-3) / 1e9, 1) if pipeline["stage_ms"][k] > 0 else 0.0
         for k in stage_bytes}
     pipeline["stage_frac_of_8TBps"] = {k: round(v / hbm_peak, 4) for k, v in pipeline["stage_algorithmic_GBps"].items()}
+    # what really limits these kernels: vector instructions issued per clock per CU against the ceiling measured for
+    # their instruction mix (tools/valu_rate.hip: ~0.9 for min/max/perm/dot/mad24, ~1.6 for add/and/shift).  Instruction
+    # counts per launch come from the committed counter pass (they do not change from run to run), times from this run
+    if sq:
+        stage_of = {"k_resize_level": ("pyramid", g.levels - 1), "k_fast_cells": ("fast_score", 1), "k_quadtree": ("quadtree", 1),
+                    "k_blur": ("blur", 1), "k_orient_describe": ("orient_describe", 1)}
+        vi = {}
+        for kname, (stage, launches) in stage_of.items():
+            ms = pipeline["stage_ms"].get(stage, 0.0)
+            valu = sq.get(kname, {}).get("SQ_INSTS_VALU")
+            if valu and ms > 0:
+                per_clk = valu * launches / (ms * 1e-3 * 2.4e9 * 256)
+                vi[kname] = {"valu_insts_per_launch": valu, "valu_per_clk_per_cu": round(per_clk, 3),
+                             "frac_of_0.9_ceiling": round(per_clk / 0.9, 3)}
+        pipeline["valu_issue"] = vi
 
     matching = {}
     if not args.no_bruteforce:

@@ -39,5 +39,17 @@ for k in sorted(set(fetch) | set(write)):
     fb = fetch.get(k, 0.0) * 1024 * f_fetch
     wb = write.get(k, 0.0) * 1024 * f_write
     res["kernels"][k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes": round(fb + wb)}
+# instruction counters of the pmc_sq pass (mean per launch), for the VALU-issue fractions bench.py prints
+sq = collections.defaultdict(dict)
+for f in glob.glob(f"{root}/pmc_sq/**/*counter_collection.csv", recursive=True):
+    acc, n = collections.defaultdict(float), collections.defaultdict(int)
+    for row in csv.DictReader(open(f)):
+        m = re.search(r"\bk_\w+", row["Kernel_Name"])
+        if m:
+            acc[(m.group(0), row["Counter_Name"])] += float(row["Counter_Value"])
+            n[(m.group(0), row["Counter_Name"])] += 1
+    for (k, c), v in acc.items():
+        sq[k][c] = round(v / n[(k, c)])
+res["sq_counters_per_launch"] = sq
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res["calibration"]), {k: v["hbm_bytes"] for k, v in res["kernels"].items()})
