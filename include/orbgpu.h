@@ -217,6 +217,31 @@ int orbgpu_match_window_segments_device(orbgpu_ctx *ctx, const orbgpu_window_arg
                                         const orbgpu_segment *d_segments, int32_t n_segments, int32_t max_to_count,
                                         int32_t *d_from_idx_per_to, uint32_t *d_dist);
 
+/* replaces: Features::AssignFeaturesToGrid / PosInGrid (features.cpp:127-161) -- the 64 x 48 search grid
+ * (constants.h:18-19) the reference means to have: the body of PosInGrid BEHIND its early `return true` (:146-148;
+ * as shipped every keypoint lands in grid[0][0]).  Range r = rows [begin, begin + count) of d_xy, given as
+ * d_ranges[2r], d_ranges[2r + 1] (one range per frame); for cell c = pos_X * 48 + pos_Y (the flat layout of
+ * grid[COLS][ROWS], features.h:36) the members are d_items[r * max_count + k], k in
+ * [d_cell_start[r * 3073 + c], d_cell_start[r * 3073 + c + 1]), as row - begin in ascending order (push_back order).
+ * max_count = the largest count (< 2^20).  Asynchronous on the context's stream. */
+#define ORBGPU_GRID_COLS 64
+#define ORBGPU_GRID_ROWS 48
+int orbgpu_grid_build_device(orbgpu_ctx *ctx, const double *d_xy, const int32_t *d_ranges, int32_t n_ranges,
+                             int32_t max_count, double image_width, double image_height, int32_t *d_cell_start,
+                             int32_t *d_items);
+
+/* replaces: orbgpu_match_window_segments_device's scan with Features::ListFeaturesInArea over that WORKING grid
+ * (features.cpp:89-123: cells of [point - window, point + window] only).  Same arguments plus max_from_count (the largest
+ * from_count) and the image size the grid is laid over (Features::image_width / image_height); same results bit for bit:
+ * the grid narrows the scan, the window / level predicate still decides, and ties keep the smallest 'from' index.  The
+ * library bins every segment's 'from' rows by cell and walks the 'to' rows along a Hilbert curve over the image, so one
+ * wavefront's windows cover few cells.  Pays off when a window covers a small part of the image (1080p / 4K frames, search
+ * by projection with radii of 15-30 px); for 640 x 480 / 1000 keypoints it is on par with the plain scan. */
+int orbgpu_match_window_grid_segments_device(orbgpu_ctx *ctx, const orbgpu_window_args *device_args,
+                                             const orbgpu_segment *d_segments, int32_t n_segments, int32_t max_to_count,
+                                             int32_t max_from_count, double image_width, double image_height,
+                                             int32_t *d_from_idx_per_to, uint32_t *d_dist);
+
 /* replaces: the matcher inside DBoW2Handler::FastMatch (features/handlers/DBoW2/dbo_w2_handler.cpp:25-72):
  * SNNMatcher<BowToIterator>, candidates restricted to features of the same vocabulary node
  * (handlers/DBoW2/bow_to_iterator.cpp:12-47, bow_to_pointee.h:37-45).  The caller joins the two

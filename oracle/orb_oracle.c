@@ -947,6 +947,63 @@ int oo_list_features_in_area(const oo_keypoint *kps, int n, double px, double py
   return m;
 }
 
+/* features.cpp:143-161, the body BEHIND the early `return true` of :146-148: the 64 x 48 grid the
+ * reference means to have.  constants.h:18-19; grid_element_*_inv_ = features.cpp:13-16. */
+void oo_pos_in_grid(double kx, double ky, double image_width, double image_height, int *posX, int *posY) {
+  const double grid_element_width_inv = (double)OO_GRID_COLS / image_width;
+  const double grid_element_height_inv = (double)OO_GRID_ROWS / image_height;
+  double x = kx > 0. ? kx : 0.; /* std::max(kp.x(), 0.) */
+  x = x < image_width ? x : image_width;
+  double y = ky > 0. ? ky : 0.;
+  y = y < image_height ? y : image_height;
+  size_t cx = (size_t)(x * grid_element_width_inv);
+  size_t cy = (size_t)(y * grid_element_height_inv);
+  *posX = (int)(cx < (size_t)(OO_GRID_COLS - 1) ? cx : (size_t)(OO_GRID_COLS - 1));
+  *posY = (int)(cy < (size_t)(OO_GRID_ROWS - 1) ? cy : (size_t)(OO_GRID_ROWS - 1));
+}
+
+/* features.cpp:127-133 with the working PosInGrid: grid[pos_X][pos_Y].push_back(i) for ascending i.  Flat layout of
+ * `std::vector<size_t> grid[COLS][ROWS]` (features.h:36): cell = pos_X * ROWS + pos_Y; items of cell c are
+ * items[cell_start[c] .. cell_start[c + 1]). */
+void oo_assign_features_to_grid(const double *xy, int n, double image_width, double image_height,
+                                int32_t *cell_start, int32_t *items) {
+  const int ncell = OO_GRID_COLS * OO_GRID_ROWS;
+  int32_t *cell_of = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
+  for (int c = 0; c <= ncell; c++) cell_start[c] = 0;
+  for (int i = 0; i < n; i++) {
+    int px, py;
+    oo_pos_in_grid(xy[2 * i], xy[2 * i + 1], image_width, image_height, &px, &py);
+    cell_of[i] = px * OO_GRID_ROWS + py;
+    cell_start[cell_of[i] + 1]++;
+  }
+  for (int c = 0; c < ncell; c++) cell_start[c + 1] += cell_start[c];
+  int32_t *cursor = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncell);
+  memcpy(cursor, cell_start, sizeof(int32_t) * (size_t)ncell);
+  for (int i = 0; i < n; i++) items[cursor[cell_of[i]]++] = i;
+  free(cursor);
+  free(cell_of);
+}
+
+/* features.cpp:81-125 as written, over the working grid: cells ix outer, iy inner, members in push_back order.
+ * Same SET as oo_list_features_in_area (the degenerate grid visits ascending j); the order differs. */
+int oo_list_features_in_area_grid(const double *xy, const int32_t *level, const int32_t *cell_start,
+                                  const int32_t *items, double image_width, double image_height, double px, double py,
+                                  size_t window, int min_level, int max_level, int32_t *out_idx) {
+  int min_cell_x, min_cell_y, max_cell_x, max_cell_y;
+  oo_pos_in_grid(px - (double)window, py - (double)window, image_width, image_height, &min_cell_x, &min_cell_y);
+  oo_pos_in_grid(px + (double)window, py + (double)window, image_width, image_height, &max_cell_x, &max_cell_y);
+  int m = 0;
+  for (int ix = min_cell_x; ix <= max_cell_x; ix++)
+    for (int iy = min_cell_y; iy <= max_cell_y; iy++) {
+      const int c = ix * OO_GRID_ROWS + iy;
+      for (int k = cell_start[c]; k < cell_start[c + 1]; k++) {
+        const int j = items[k];
+        if (window_pred(xy[2 * j], xy[2 * j + 1], level[j], px, py, window, min_level, max_level)) out_idx[m++] = j;
+      }
+    }
+  return m;
+}
+
 int oo_snn_match(const oo_match_args *a, int32_t *match_from, uint32_t *match_dist) {
   /* second_nearest_neighbor_matcher.hpp:30-80 */
   uint32_t *best_from_dist = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(a->n_from ? a->n_from : 1));

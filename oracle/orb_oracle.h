@@ -128,6 +128,16 @@ unsigned oo_hamming256(const uint8_t *a, const uint8_t *b);
 int oo_list_features_in_area(const oo_keypoint *kps, int n, double px, double py, size_t window, int min_level,
                              int max_level, int32_t *out_idx);
 
+/* the 64 x 48 search grid behind PosInGrid's early return (features.cpp:127-161, constants.h:18-19) */
+#define OO_GRID_COLS 64
+#define OO_GRID_ROWS 48
+void oo_pos_in_grid(double kx, double ky, double image_width, double image_height, int *posX, int *posY);
+void oo_assign_features_to_grid(const double *xy, int n, double image_width, double image_height,
+                                int32_t *cell_start, int32_t *items);
+int oo_list_features_in_area_grid(const double *xy, const int32_t *level, const int32_t *cell_start,
+                                  const int32_t *items, double image_width, double image_height, double px, double py,
+                                  size_t window, int min_level, int max_level, int32_t *out_idx);
+
 /* SNNMatcher::MatchWithIterators second_nearest_neighbor_matcher.hpp:30-80.
  * Generic form: for 'to' i (in order, skipping to_active[i]==0 when given) candidates are the 'from' j
  * (ascending) that pass the window predicate (when to_xy != NULL) -- see oo_list_features_in_area.

@@ -228,6 +228,30 @@ def list_features_in_area(kps, px, py, window, min_level, max_level):
     return out[:n].copy()
 
 
+GRID_COLS, GRID_ROWS = 64, 48
+
+
+def assign_features_to_grid(xy, width, height):
+    """Features::AssignFeaturesToGrid over the working PosInGrid: (cell_start[3073], items[n]), cell = ix * 48 + iy."""
+    xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+    cs = np.zeros(GRID_COLS * GRID_ROWS + 1, np.int32)
+    items = np.zeros(max(len(xy), 1), np.int32)
+    lib().oo_assign_features_to_grid(_p(xy), len(xy), C.c_double(width), C.c_double(height), _p(cs), _p(items))
+    return cs, items[:len(xy)].copy()
+
+
+def list_features_in_area_grid(xy, level, cell_start, items, width, height, px, py, window, min_level, max_level):
+    xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+    level = np.ascontiguousarray(level, np.int32)
+    cell_start = np.ascontiguousarray(cell_start, np.int32)
+    items = np.ascontiguousarray(items, np.int32)
+    out = np.empty(len(xy) + 1, np.int32)
+    n = lib().oo_list_features_in_area_grid(_p(xy), _p(level), _p(cell_start), _p(items), C.c_double(width),
+                                            C.c_double(height), C.c_double(px), C.c_double(py), C.c_size_t(int(window)),
+                                            int(min_level), int(max_level), _p(out))
+    return out[:n].copy()
+
+
 def snn_match(to_desc, from_desc, threshold, ratio, to_xy=None, to_window=None, to_min_level=None,
               to_max_level=None, to_active=None, from_xy=None, from_level=None):
     to_desc = np.ascontiguousarray(to_desc, np.uint8).reshape(-1, 32)

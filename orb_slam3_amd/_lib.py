@@ -69,7 +69,8 @@ EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_g
            "orbgpu_synchronize", "orbgpu_set_stream", "orbgpu_set_batch_slices", "orbgpu_wait_event", "orbgpu_record_event", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
            "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_bruteforce_noalloc_device",
            "orbgpu_match_window",
-           "orbgpu_match_window_device", "orbgpu_match_window_segments_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
+           "orbgpu_match_window_device", "orbgpu_match_window_segments_device", "orbgpu_grid_build_device",
+           "orbgpu_match_window_grid_segments_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
            "orbgpu_match_allpairs_device", "orbgpu_vocab_create", "orbgpu_vocab_destroy", "orbgpu_bow_transform",
            "orbgpu_bow_transform_device", "orbgpu_distinctive_descriptor", "orbgpu_distinctive_descriptor_device",
            "orbgpu_keypoint_geometry", "orbgpu_keypoint_geometry_device", "orbgpu_bow_score", "orbgpu_bow_score_device",
@@ -112,6 +113,8 @@ def load():
         "orbgpu_match_window": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_window_device": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_window_segments_device": (i32, [vp, C.POINTER(WindowArgs), vp, i32, i32, vp, vp]),
+        "orbgpu_grid_build_device": (i32, [vp, vp, vp, i32, i32, dbl, dbl, vp, vp]),
+        "orbgpu_match_window_grid_segments_device": (i32, [vp, C.POINTER(WindowArgs), vp, i32, i32, i32, dbl, dbl, vp, vp]),
         "orbgpu_match_frames_device": (i32, [vp, vp, vp, vp, i32, vp, vp, i32, u64, u32, dbl, i32, vp, vp, vp]),
         "orbgpu_match_groups": (i32, [vp, C.POINTER(GroupArgs), vp, vp]),
         "orbgpu_match_groups_device": (i32, [vp, C.POINTER(GroupArgs), i32, vp, vp]),

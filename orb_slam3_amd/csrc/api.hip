@@ -325,7 +325,6 @@ struct Staging {
     return d;
   }
 };
-inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 }  // namespace
 
 extern "C" {
@@ -827,6 +826,56 @@ int orbgpu_match_window_segments_device(orbgpu_ctx *ctx, const orbgpu_window_arg
   if (rc) return rc;
   launch_match_segments(ctx, *a, d_segments, n_segments, max_to_count, a->n_from, d_from_idx_per_to,
                         reinterpret_cast<unsigned *>(d_dist), ctx->d_match_scratch);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
+int orbgpu_grid_build_device(orbgpu_ctx *ctx, const double *d_xy, const int32_t *d_ranges, int32_t n_ranges,
+                             int32_t max_count, double image_width, double image_height, int32_t *d_cell_start,
+                             int32_t *d_items) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (n_ranges < 0 || max_count < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (!(image_width > 0.0) || !(image_height > 0.0)) return fail(ctx, ORBGPU_E_INVALID, "image size must be positive");
+  if (max_count >= (1 << 20)) return fail(ctx, ORBGPU_E_INVALID, "a grid range must hold fewer than 2^20 rows");
+  if (n_ranges == 0) return ORBGPU_OK;
+  if (!d_ranges || !d_cell_start || (max_count > 0 && (!d_xy || !d_items))) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = ensure_match_scratch(ctx, grid_build_scratch_bytes(n_ranges, std::max(max_count, 1)));
+  if (rc) return rc;
+  launch_grid_build(ctx, d_xy, d_ranges, n_ranges, max_count, image_width, image_height, d_cell_start, d_items,
+                    ctx->d_match_scratch);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
+int orbgpu_match_window_grid_segments_device(orbgpu_ctx *ctx, const orbgpu_window_args *a, const orbgpu_segment *d_segments,
+                                             int32_t n_segments, int32_t max_to_count, int32_t max_from_count,
+                                             double image_width, double image_height, int32_t *d_from_idx_per_to,
+                                             uint32_t *d_dist) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (n_segments < 0 || max_to_count < 0 || max_from_count < 0 || a->n_to < 0 || a->n_from < 0)
+    return fail(ctx, ORBGPU_E_INVALID, "negative count");
+  if (!(image_width > 0.0) || !(image_height > 0.0)) return fail(ctx, ORBGPU_E_INVALID, "image size must be positive");
+  if (n_segments == 0 || max_to_count == 0) return ORBGPU_OK;
+  if (!d_segments || !a->to_desc || !a->to_xy || !a->to_window || !a->to_min_level || !a->to_max_level || !d_from_idx_per_to ||
+      !d_dist)
+    return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_from > 0 && (!a->from_desc || !a->from_xy || !a->from_level)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (a->n_from >= (1 << 23)) return fail(ctx, ORBGPU_E_INVALID, "a segment's from_count must be below 2^23");
+  if (max_to_count >= (1 << 20) || max_from_count >= (1 << 20))
+    return fail(ctx, ORBGPU_E_INVALID, "a grid range must hold fewer than 2^20 rows");
+  if (!(a->ratio >= 0.0)) return fail(ctx, ORBGPU_E_INVALID, "ratio must be >= 0");
+  if (n_segments > 65535) return fail(ctx, ORBGPU_E_INVALID, "more than 65535 segments in one call");
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc = ensure_match_scratch(ctx, grid_match_scratch_bytes(n_segments, max_to_count, std::max(max_from_count, 1),
+                                                              std::max(a->n_from, 1)));
+  if (rc) return rc;
+  launch_match_grid_segments(ctx, *a, d_segments, n_segments, max_to_count, std::max(max_from_count, 1), a->n_from,
+                             image_width, image_height, d_from_idx_per_to, reinterpret_cast<unsigned *>(d_dist),
+                             ctx->d_match_scratch);
   HIP_TRY(hipGetLastError());
   return ORBGPU_OK;
 }

@@ -237,7 +237,10 @@ __global__ __launch_bounds__(256) void k_snn_segments(orbgpu_window_args a, cons
   if (!live) return;
   unsigned d = 0;
   int j = snn_accept(best, second, a.threshold, a.ratio, d);
-  if (a.to_active && !a.to_active[i]) j = -1;
+  if (a.to_active && !a.to_active[i]) {
+    j = -1;
+    d = 0;
+  }
   from_idx[i] = j;
   dist[i] = d;
   if (j >= 0) atomicMin(&claim[sg.from_begin + j], ((unsigned long long)d << 32) | (unsigned)li);
@@ -253,6 +256,290 @@ __global__ __launch_bounds__(256) void k_snn_segments_resolve(const orbgpu_segme
   const int i = sg.to_begin + li;
   const int j = from_idx[i];
   if (j >= 0 && claim[sg.from_begin + j] != (((unsigned long long)dist[i] << 32) | (unsigned)li)) from_idx[i] = -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 64 x 48 search grid of Features (features.cpp:127-161: AssignFeaturesToGrid over the body of PosInGrid behind
+// its early return) as a device-side index, and the windowed matcher over it.  The grid only narrows the scan: the
+// candidate set of a 'to' row is decided by the same window / level predicate as everywhere else and ties are broken
+// by the original 'from' index inside the packed key, so the results are those of k_snn_segments bit for bit.
+constexpr int GRID_COLS = 64, GRID_ROWS = 48, GRID_CELLS = GRID_COLS * GRID_ROWS, GRID_BINS = 4096;
+constexpr int GRID_ITEM_BITS = 20;  // a range holds fewer than 2^20 rows: (bin << 20 | row) fits an int
+
+struct GridDims {
+  double w, h, inv_w, inv_h;  // image_width, image_height, grid_element_width_inv_, grid_element_height_inv_
+};
+
+// features.cpp:150-158
+__device__ __forceinline__ int2 pos_in_grid(double kx, double ky, const GridDims &g) {
+  double x = kx > 0.0 ? kx : 0.0;
+  x = x < g.w ? x : g.w;
+  double y = ky > 0.0 ? ky : 0.0;
+  y = y < g.h ? y : g.h;
+  return make_int2(min(GRID_COLS - 1, (int)(x * g.inv_w)), min(GRID_ROWS - 1, (int)(y * g.inv_h)));
+}
+
+// Position along a 64 x 64 Hilbert curve laid over the image (x, y in 0..63): rows that follow each other on the curve
+// are neighbours in the image, so 64 consecutive rows form one compact patch (a Morton order jumps between patches).
+__device__ __forceinline__ int hilbert64(int x, int y) {
+  int d = 0;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    const int rx = (x & s) ? 1 : 0, ry = (y & s) ? 1 : 0;
+    d += s * s * ((3 * rx) ^ ry);
+    if (ry == 0) {
+      if (rx) {
+        x = 63 - x;
+        y = 63 - y;
+      }
+      const int tq = x;
+      x = y;
+      y = tq;
+    }
+  }
+  return d;
+}
+
+// One workgroup per range: rows [begin, begin + count) of xy, binned by grid cell (cell = ix * 48 + iy, the flat layout
+// of grid[COLS][ROWS]; CURVE: by position along a Hilbert curve over the image), ascending row index inside a bin
+// (push_back order).
+// ranges: n x range_stride ints, (begin, count) at range_off.  Outputs for range r at out = r * out_stride:
+// items[out + k] = row - begin in bin order, cell_start[r * (GRID_CELLS + 1) + c] (not CURVE), and with GATHER the
+// rows' descriptor / position / level copied into bin order (the matcher then scans contiguous arrays).
+constexpr int GB_THREADS = 1024, GB_PER = GRID_BINS / GB_THREADS;
+
+struct GridBuildArgs {
+  const double2 *xy;
+  const int *ranges;
+  int range_stride, range_off, out_stride;
+  int *tmp, *items, *cell_start;
+  const uint4 *desc;  // GATHER only
+  const int *level;
+  uint4 *s_desc;
+  double2 *s_xy;
+  int *s_lv;
+};
+
+template <bool CURVE, bool GATHER>
+__device__ __forceinline__ void grid_build_body(const GridBuildArgs &a, const GridDims &g, int r, int *hist, int *cursor,
+                                                int *wsum) {
+  const int tid = threadIdx.x;
+  const int begin = a.ranges[r * a.range_stride + a.range_off], count = a.ranges[r * a.range_stride + a.range_off + 1];
+  const size_t out = (size_t)r * a.out_stride;
+  const double2 *__restrict__ xy = a.xy + begin;
+  int *__restrict__ tmp = a.tmp + out;
+  for (int b = tid; b < GRID_BINS; b += GB_THREADS) hist[b] = 0;
+  __syncthreads();
+  auto bin_of = [&](int i) {
+    const double2 p = xy[i];
+    const int2 c = pos_in_grid(p.x, p.y, g);
+    if (!CURVE) return c.x * GRID_ROWS + c.y;
+    // ordering only: a 64 x 64 lattice over the image, independent of the search grid
+    double y = p.y > 0.0 ? p.y : 0.0;
+    y = y < g.h ? y : g.h;
+    return hilbert64(c.x, min(63, (int)(y * (64.0 / g.h))));
+  };
+  for (int i = tid; i < count; i += GB_THREADS) atomicAdd(&hist[bin_of(i)], 1);
+  __syncthreads();
+  // exclusive scan over the bins: GB_PER consecutive bins per thread, then the thread sums
+  int local[GB_PER], sum = 0;
+#pragma unroll
+  for (int k = 0; k < GB_PER; k++) {
+    local[k] = sum;
+    sum += hist[tid * GB_PER + k];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d);
+    if ((tid & 63) >= d) incl += v;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int base = incl - sum;
+  for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+#pragma unroll
+  for (int k = 0; k < GB_PER; k++) cursor[tid * GB_PER + k] = base + local[k];
+  __syncthreads();
+  if (!CURVE && a.cell_start) {
+    int *cs = a.cell_start + (size_t)r * (GRID_CELLS + 1);
+    for (int b = tid; b < GRID_CELLS; b += GB_THREADS) cs[b] = cursor[b];
+    if (tid == 0) cs[GRID_CELLS] = count;
+  }
+  for (int i = tid; i < count; i += GB_THREADS) {
+    const int b = bin_of(i);
+    tmp[atomicAdd(&cursor[b], 1)] = (int)(((unsigned)b << GRID_ITEM_BITS) | (unsigned)i);  // arrival order inside the bin
+  }
+  __syncthreads();  // tmp of this workgroup is complete; cursor[b] = end of bin b, cursor[b] - hist[b] = its start
+  for (int k = tid; k < count; k += GB_THREADS) {
+    const unsigned e = (unsigned)tmp[k];
+    const int b = (int)(e >> GRID_ITEM_BITS), i = (int)(e & ((1u << GRID_ITEM_BITS) - 1u));
+    const int b1 = cursor[b], b0 = b1 - hist[b];
+    int rank = 0;
+    for (int q = b0; q < b1; q++) rank += (tmp[q] & ((1 << GRID_ITEM_BITS) - 1)) < i;
+    const size_t dst = out + b0 + rank;
+    a.items[dst] = i;
+    if (GATHER) {
+      a.s_desc[2 * dst] = a.desc[2 * (size_t)(begin + i)];
+      a.s_desc[2 * dst + 1] = a.desc[2 * (size_t)(begin + i) + 1];
+      a.s_xy[dst] = xy[i];
+      a.s_lv[dst] = a.level[begin + i];
+    }
+  }
+}
+
+// the grid by itself (orbgpu_grid_build_device): grid = ranges
+__global__ __launch_bounds__(GB_THREADS) void k_grid_build(GridBuildArgs a, GridDims g) {
+  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64];
+  grid_build_body<false, false>(a, g, blockIdx.x, hist, cursor, wsum);
+}
+
+// both sides of a batch of window searches in one launch: grid = (segments, 2); y = 0 bins the 'from' rows by cell and
+// gathers their copies, y = 1 orders the 'to' rows along the curve
+__global__ __launch_bounds__(GB_THREADS) void k_grid_build_pair(GridBuildArgs from, GridBuildArgs to, GridDims g) {
+  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64];
+  if (blockIdx.y == 0)
+    grid_build_body<false, true>(from, g, blockIdx.x, hist, cursor, wsum);
+  else
+    grid_build_body<true, false>(to, g, blockIdx.x, hist, cursor, wsum);
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// grid: x = 256-row blocks of a segment's 'to' rows in Hilbert order over the image, y = segment.  A wave's 64 'to' rows
+// lie in a compact patch, so the union of their windows covers few grid cells: per grid column ix of that union the
+// cells iy_min..iy_max are ONE contiguous run of the binned 'from' copies.  The runs of all columns, laid end to end, are
+// fetched 64 candidates at a time (one per lane, the next 64 in flight while these are evaluated) and every candidate is
+// broadcast with v_readlane: a scalar load per candidate would pay the full memory latency once per iteration (the
+// copies of a batch do not fit L2).
+__global__ __launch_bounds__(256) void k_snn_grid(orbgpu_window_args a, const orbgpu_segment *__restrict__ segs,
+                                                  GridDims g, int to_stride, int from_stride,
+                                                  const int *__restrict__ to_items, const int *__restrict__ cell_start,
+                                                  const int *__restrict__ s_idx, const uint4 *__restrict__ s_desc,
+                                                  const double2 *__restrict__ s_xy, const int *__restrict__ s_lv,
+                                                  int *__restrict__ from_idx, unsigned *__restrict__ dist,
+                                                  unsigned long long *__restrict__ claim) {
+  const orbgpu_segment sg = segs[blockIdx.y];
+  if ((int)(blockIdx.x * 256) >= sg.to_count) return;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < sg.to_count;
+  const int li = to_items[(size_t)blockIdx.y * to_stride + min(p, sg.to_count - 1)];
+  const int i = sg.to_begin + li;
+  const uint4 *td = reinterpret_cast<const uint4 *>(a.to_desc) + 2 * (size_t)i;
+  const uint4 t0 = td[0], t1 = td[1];
+  const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  ToWindow tw;
+  tw.x = a.to_xy[2 * (size_t)i];
+  tw.y = a.to_xy[2 * (size_t)i + 1];
+  tw.win = (double)a.to_window[i];
+  tw.lmin = a.to_min_level[i];
+  tw.lmax = a.to_max_level[i];
+  tw.check_levels = (tw.lmin > 0) || (tw.lmax >= 0);  // features.cpp:94
+  const bool active = live && !(a.to_active && !a.to_active[i]);
+  const int lane = threadIdx.x & 63;
+  // features.cpp:91-92
+  const int2 lo = pos_in_grid(tw.x - tw.win, tw.y - tw.win, g), hi = pos_in_grid(tw.x + tw.win, tw.y + tw.win, g);
+  const int x0 = wave_min_i(active ? lo.x : GRID_COLS), x1 = wave_max_i(active ? hi.x : -1);
+  const int *__restrict__ cs = cell_start + (size_t)blockIdx.y * (GRID_CELLS + 1);
+  const size_t fb = (size_t)blockIdx.y * from_stride;
+  const uint4 *__restrict__ fd = s_desc + 2 * fb;
+  const double2 *__restrict__ fxy = s_xy + fb;
+  const int *__restrict__ flv = s_lv + fb;
+  const int *__restrict__ fid = s_idx + fb;
+  unsigned best = KEY_NONE, second = KEY_NONE;
+  auto rl = [](unsigned v, int c) { return (unsigned)__builtin_amdgcn_readlane((int)v, c); };
+  auto rld = [&](double v, int c) {
+    const unsigned long long u = __double_as_longlong(v);
+    return __longlong_as_double((long long)(((unsigned long long)rl((unsigned)(u >> 32), c) << 32) | rl((unsigned)u, c)));
+  };
+  // per grid column of the union, the cell rows some lane of this wave needs (a bounding box would also scan the
+  // corners nobody looks at)
+  __shared__ int col_y0[4][GRID_COLS], col_y1[4][GRID_COLS];
+  const int wv = threadIdx.x >> 6;
+  col_y0[wv][lane] = GRID_ROWS;
+  col_y1[wv][lane] = -1;
+  __syncthreads();
+  if (active)
+    for (int ix = lo.x; ix <= hi.x; ix++) {
+      atomicMin(&col_y0[wv][ix], lo.y);
+      atomicMax(&col_y1[wv][ix], hi.y);
+    }
+  __syncthreads();
+  // lane l = grid column x0 + l of the union: its run [k0, k1) of binned 'from' rows, and the runs laid end to end
+  const int ncols = x1 - x0 + 1;  // <= 64; <= 0 when no lane is active
+  int run0 = 0, run_len = 0;
+  if (lane < ncols) {
+    const int cy0 = col_y0[wv][x0 + lane], cy1 = col_y1[wv][x0 + lane];
+    if (cy0 <= cy1) {
+      run0 = cs[(x0 + lane) * GRID_ROWS + cy0];
+      run_len = cs[(x0 + lane) * GRID_ROWS + cy1 + 1] - run0;
+    }
+  }
+  int run_end = run_len;  // inclusive scan
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const int v = __shfl_up(run_end, dlt);
+    if (lane >= dlt) run_end += v;
+  }
+  const int total = ncols > 0 ? __builtin_amdgcn_readlane(run_end, 63) : 0;
+  struct Cand {
+    double2 xy;
+    int lv;
+    unsigned id;
+    uint4 a, b;
+  };
+  // candidate f of the concatenated runs -> its row: the column is the number of runs that end at or before f
+  auto fetch = [&](int f0) {
+    const int f = min(f0 + lane, total - 1);
+    int col = 0;
+    for (int l = 0; l < ncols; l++) col += rl((unsigned)run_end, l) <= (unsigned)f ? 1 : 0;
+    const int k = __shfl(run0, col) + (f - (__shfl(run_end, col) - __shfl(run_len, col)));
+    Cand c;
+    c.xy = fxy[k];
+    c.lv = flv[k];
+    c.id = (unsigned)fid[k];
+    c.a = fd[2 * k];
+    c.b = fd[2 * k + 1];
+    return c;
+  };
+  if (total > 0) {
+    Cand cur = fetch(0);
+    for (int f0 = 0; f0 < total; f0 += 64) {
+      Cand nxt = cur;
+      if (f0 + 64 < total) nxt = fetch(f0 + 64);  // in flight while the current 64 are evaluated
+      const int cnt = min(64, total - f0);
+      for (int c = 0; c < cnt; c++) {
+        const bool ok = active && window_ok(tw, make_double2(rld(cur.xy.x, c), rld(cur.xy.y, c)), (int)rl((unsigned)cur.lv, c));
+        if (!__ballot(ok)) continue;
+        const uint4 fa = make_uint4(rl(cur.a.x, c), rl(cur.a.y, c), rl(cur.a.z, c), rl(cur.a.w, c));
+        const uint4 fb4 = make_uint4(rl(cur.b.x, c), rl(cur.b.y, c), rl(cur.b.z, c), rl(cur.b.w, c));
+        unsigned key = (hamming8(t, fa, fb4) << IDX_BITS) | rl(cur.id, c);
+        key = ok ? key : KEY_NONE;
+        second = umed3(best, key, second);
+        best = min(best, key);
+      }
+      cur = nxt;
+    }
+  }
+  if (!live) return;
+  unsigned d = 0;
+  int j = snn_accept(best, second, a.threshold, a.ratio, d);
+  if (!active) {
+    j = -1;
+    d = 0;
+  }
+  from_idx[i] = j;
+  dist[i] = d;
+  if (j >= 0) atomicMin(&claim[sg.from_begin + j], ((unsigned long long)d << 32) | (unsigned)li);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -974,6 +1261,89 @@ void launch_match_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, con
   b.threshold = std::min(a.threshold, 256u);
   const dim3 grid((max_to_count + 255) / 256, n_segments);
   hipLaunchKernelGGL(k_snn_segments, grid, dim3(256), 0, c->stream, b, d_segs, d_from_idx, d_dist, claim);
+  hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim);
+}
+
+static GridDims grid_dims(double image_width, double image_height) {
+  // features.cpp:13-16
+  return GridDims{image_width, image_height, (double)GRID_COLS / image_width, (double)GRID_ROWS / image_height};
+}
+
+size_t grid_build_scratch_bytes(int n_ranges, int max_count) { return (size_t)n_ranges * max_count * 4 + 256; }
+
+// the grid by itself: ranges = n x (begin, count); items[r * max_count + k] (row - begin), cell_start[r][3073]
+void launch_grid_build(const orbgpu_ctx *c, const double *d_xy, const int *d_ranges, int n_ranges, int max_count,
+                       double image_width, double image_height, int *d_cell_start, int *d_items, void *scratch) {
+  GridBuildArgs ga{};
+  ga.xy = reinterpret_cast<const double2 *>(d_xy);
+  ga.ranges = d_ranges;
+  ga.range_stride = 2;
+  ga.range_off = 0;
+  ga.out_stride = max_count;
+  ga.tmp = reinterpret_cast<int *>(scratch);
+  ga.items = d_items;
+  ga.cell_start = d_cell_start;
+  hipLaunchKernelGGL(k_grid_build, dim3(n_ranges), dim3(GB_THREADS), 0, c->stream, ga, grid_dims(image_width, image_height));
+}
+
+size_t grid_match_scratch_bytes(int n_segments, int max_to_count, int max_from_count, int n_from_total) {
+  const size_t nt = (size_t)n_segments * max_to_count, nf = (size_t)n_segments * max_from_count;
+  return pad256((size_t)n_from_total * 8) + pad256(nt * 4) + pad256(nt * 4) + pad256(nf * 4) +
+         pad256((size_t)n_segments * (GRID_CELLS + 1) * 4) + pad256(nf * 4) + pad256(nf * 4) + pad256(nf * 16) +
+         pad256(nf * 32) + 256;
+}
+
+void launch_match_grid_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, const orbgpu_segment *d_segs,
+                                int n_segments, int max_to_count, int max_from_count, int n_from_total,
+                                double image_width, double image_height, int *d_from_idx, unsigned *d_dist, void *scratch) {
+  const size_t nt = (size_t)n_segments * max_to_count, nf = (size_t)n_segments * max_from_count;
+  unsigned char *sp = reinterpret_cast<unsigned char *>(scratch);
+  auto take = [&](size_t bytes) {
+    void *q = sp;
+    sp += pad256(bytes);
+    return q;
+  };
+  unsigned long long *claim = reinterpret_cast<unsigned long long *>(take((size_t)n_from_total * 8));
+  int *to_items = reinterpret_cast<int *>(take(nt * 4));
+  int *tmp_to = reinterpret_cast<int *>(take(nt * 4));
+  int *tmp_from = reinterpret_cast<int *>(take(nf * 4));
+  int *cell_start = reinterpret_cast<int *>(take((size_t)n_segments * (GRID_CELLS + 1) * 4));
+  int *s_idx = reinterpret_cast<int *>(take(nf * 4));
+  int *s_lv = reinterpret_cast<int *>(take(nf * 4));
+  double2 *s_xy = reinterpret_cast<double2 *>(take(nf * 16));
+  uint4 *s_desc = reinterpret_cast<uint4 *>(take(nf * 32));
+  (void)hipMemsetAsync(claim, 0xff, (size_t)n_from_total * sizeof(unsigned long long), c->stream);
+  const GridDims g = grid_dims(image_width, image_height);
+  const int *ranges = reinterpret_cast<const int *>(d_segs);
+  // 'from' rows of every segment: binned by cell, copies in bin order; 'to' rows: Hilbert order over the image (only
+  // the order is used)
+  GridBuildArgs gf{}, gt{};
+  gf.xy = reinterpret_cast<const double2 *>(a.from_xy);
+  gf.ranges = ranges;
+  gf.range_stride = 4;
+  gf.range_off = 2;
+  gf.out_stride = max_from_count;
+  gf.tmp = tmp_from;
+  gf.items = s_idx;
+  gf.cell_start = cell_start;
+  gf.desc = reinterpret_cast<const uint4 *>(a.from_desc);
+  gf.level = a.from_level;
+  gf.s_desc = s_desc;
+  gf.s_xy = s_xy;
+  gf.s_lv = s_lv;
+  gt.xy = reinterpret_cast<const double2 *>(a.to_xy);
+  gt.ranges = ranges;
+  gt.range_stride = 4;
+  gt.range_off = 0;
+  gt.out_stride = max_to_count;
+  gt.tmp = tmp_to;
+  gt.items = to_items;
+  hipLaunchKernelGGL(k_grid_build_pair, dim3(n_segments, 2), dim3(GB_THREADS), 0, c->stream, gf, gt, g);
+  orbgpu_window_args b = a;
+  b.threshold = std::min(a.threshold, 256u);
+  const dim3 grid((max_to_count + 255) / 256, n_segments);
+  hipLaunchKernelGGL(k_snn_grid, grid, dim3(256), 0, c->stream, b, d_segs, g, max_to_count, max_from_count, to_items,
+                     cell_start, s_idx, s_desc, s_xy, s_lv, d_from_idx, d_dist, claim);
   hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim);
 }
 

@@ -210,6 +210,14 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
                          int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
                          unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,
                          int *d_n_matches);
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+size_t grid_build_scratch_bytes(int n_ranges, int max_count);
+void launch_grid_build(const orbgpu_ctx *c, const double *d_xy, const int *d_ranges, int n_ranges, int max_count,
+                       double image_width, double image_height, int *d_cell_start, int *d_items, void *scratch);
+size_t grid_match_scratch_bytes(int n_segments, int max_to_count, int max_from_count, int n_from_total);
+void launch_match_grid_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, const orbgpu_segment *d_segs,
+                                int n_segments, int max_to_count, int max_from_count, int n_from_total,
+                                double image_width, double image_height, int *d_from_idx, unsigned *d_dist, void *scratch);
 void launch_match_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, const orbgpu_segment *d_segs, int n_segments,
                            int max_to_count, int n_from_total, int *d_from_idx, unsigned *d_dist, void *scratch);
 size_t group_scratch_bytes(int n_from, int n_slots);

@@ -346,3 +346,123 @@ def test_window_segments_parity(oracle, fe):
             assert (gi[s * cap_to + nt:(s + 1) * cap_to] == 777).all()       # rows outside the segment are not written
             total += int(sel.sum())
         assert total > 300
+
+
+def test_grid_build_matches_assign_features_to_grid(oracle, fe):
+    """orbgpu_grid_build_device against the oracle's Features::AssignFeaturesToGrid over the WORKING PosInGrid
+    (features.cpp:127-161): cell boundaries, clamping of out-of-image points, ascending order inside a cell, ragged and
+    empty ranges, one crowded cell."""
+    import torch
+    from orb_slam3_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    W, H = 1920.0, 1080.0
+    counts = [5000, 0, 1, 777, 3000]
+    cap = max(counts)
+    xy = np.zeros((len(counts) * cap, 2))
+    ranges = np.zeros((len(counts), 2), np.int32)
+    for r, n in enumerate(counts):
+        ranges[r] = (r * cap, n)
+        pts = rng.uniform((-40, -40), (W + 40, H + 40), (n, 2))          # some outside the image: clamped to the border cells
+        if n >= 777:
+            pts[:64] = np.floor(pts[:64] / (W / 64)) * (W / 64)           # exactly on cell boundaries (x)
+            pts[64:128, 1] = np.floor(pts[64:128, 1] / (H / 48)) * (H / 48)
+            pts[128:140] = (W, H)                                         # the far corner: min(COLS - 1, ...)
+        if n == 3000:
+            pts[1000:2500] = rng.uniform((300, 300), (310, 310), (1500, 2))   # a crowded cell
+        xy[r * cap:r * cap + n] = pts
+    dev = torch.device("cuda", 0)
+    d_xy, d_r = torch.from_numpy(xy).to(dev), torch.from_numpy(ranges).to(dev)
+    d_cs = torch.full((len(counts), 3073), -5, dtype=torch.int32, device=dev)
+    d_it = torch.full((len(counts), cap), -5, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for rep in range(2):
+        rc = lib.orbgpu_grid_build_device(fe.handle, d_xy.data_ptr(), d_r.data_ptr(), len(counts), cap, W, H,
+                                          d_cs.data_ptr(), d_it.data_ptr())
+        assert rc == 0, lib.orbgpu_last_error(fe.handle)
+    assert lib.orbgpu_synchronize(fe.handle) == 0
+    cs, it = d_cs.cpu().numpy(), d_it.cpu().numpy()
+    for r, n in enumerate(counts):
+        ocs, oit = oracle.assign_features_to_grid(xy[r * cap:r * cap + n], W, H)
+        assert np.array_equal(cs[r], ocs), r
+        assert np.array_equal(it[r, :n], oit), r
+        assert (it[r, n:] == -5).all()
+    assert np.diff(cs[4]).max() >= 1500
+
+
+@pytest.mark.parametrize("W,H,n_kp,radius", [(640, 480, 1000, 24.0), (1920, 1080, 5000, 15.0), (1920, 1080, 5000, 100.0),
+                                             (3840, 2160, 3000, 30.0)])
+def test_grid_window_segments_parity(oracle, fe, W, H, n_kp, radius):
+    """orbgpu_match_window_grid_segments_device = orbgpu_match_window_segments_device = the oracle, on ragged segments
+    with planted matches, ties, contested claims, inactive rows, keypoints outside the image and windows that reach
+    over the border."""
+    import ctypes as C
+    import torch
+    from orb_slam3_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(int(W + n_kp + radius))
+    sizes = [(n_kp, n_kp), (0, 50), (1, 1), (n_kp // 2, 0), (n_kp // 3, n_kp), (257, n_kp - 7)]
+    cap = n_kp
+    S = len(sizes)
+    to_desc = rng.integers(0, 256, (S * cap, 32), dtype=np.uint8)
+    from_desc = rng.integers(0, 256, (S * cap, 32), dtype=np.uint8)
+    to_xy = rng.uniform((-20, -20), (W + 20, H + 20), (S * cap, 2))
+    from_xy = rng.uniform((-20, -20), (W + 20, H + 20), (S * cap, 2))
+    to_lv = rng.integers(0, 8, S * cap).astype(np.int32)
+    from_lv = rng.integers(0, 8, S * cap).astype(np.int32)
+    active = (rng.uniform(size=S * cap) < 0.9).astype(np.uint8)
+    segs = np.zeros(S, _lib.SEGMENT_DTYPE)
+    for s, (nt, nf) in enumerate(sizes):
+        segs[s] = (s * cap, nt, s * cap, nf)
+        k = min(nt, nf)
+        if k:
+            j = rng.choice(nf, k, replace=False)
+            i = rng.choice(nt, k, replace=False)
+            to_desc[s * cap + i] = from_desc[s * cap + j]
+            to_desc[s * cap + i, :2] ^= rng.integers(0, 256, (k, 2)).astype(np.uint8)
+            to_xy[s * cap + i] = from_xy[s * cap + j] + rng.uniform(-5, 5, (k, 2))
+            to_lv[s * cap + i] = np.clip(from_lv[s * cap + j] + rng.integers(-1, 2, k), 0, 7)
+            if k > 8:
+                for q in (1, 2):                                      # contested claim, best == second tie
+                    to_desc[s * cap + i[q]] = to_desc[s * cap + i[0]]
+                    to_xy[s * cap + i[q]] = to_xy[s * cap + i[0]]
+                    to_lv[s * cap + i[q]] = to_lv[s * cap + i[0]]
+                from_desc[s * cap + j[3]] = from_desc[s * cap + j[4]]   # equal distances: the smaller index must win
+                from_xy[s * cap + j[3]] = from_xy[s * cap + j[4]]
+                from_lv[s * cap + j[3]] = from_lv[s * cap + j[4]]
+    win = (np.float64(radius) * np.float64(1.2) ** to_lv).astype(np.uint64)
+    lmin, lmax = np.maximum(to_lv - 1, 0).astype(np.int32), (to_lv + 1).astype(np.int32)
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in dict(
+        to_desc=to_desc, from_desc=from_desc, to_xy=to_xy, from_xy=from_xy, win=win.view(np.int64), lmin=lmin, lmax=lmax,
+        from_lv=from_lv, active=active, segs=segs.view(np.int32).reshape(S, 4)).items()}
+    out = [(torch.full((S * cap,), 777, dtype=torch.int32, device=dev), torch.full((S * cap,), 777, dtype=torch.int32, device=dev))
+           for _ in range(2)]
+    torch.cuda.synchronize()
+    max_to, max_from = max(nt for nt, _ in sizes), max(nf for _, nf in sizes)
+    for th, ratio in ((100, 0.9), (50, 1.0)):
+        a = _lib.WindowArgs(t["to_desc"].data_ptr(), t["to_xy"].data_ptr(), t["win"].data_ptr(), t["lmin"].data_ptr(),
+                            t["lmax"].data_ptr(), t["active"].data_ptr(), S * cap, t["from_desc"].data_ptr(),
+                            t["from_xy"].data_ptr(), t["from_lv"].data_ptr(), S * cap, th, ratio)
+        rc = lib.orbgpu_match_window_segments_device(fe.handle, C.byref(a), t["segs"].data_ptr(), S, max_to,
+                                                     out[0][0].data_ptr(), out[0][1].data_ptr())
+        assert rc == 0, lib.orbgpu_last_error(fe.handle)
+        rc = lib.orbgpu_match_window_grid_segments_device(fe.handle, C.byref(a), t["segs"].data_ptr(), S, max_to, max_from,
+                                                          float(W), float(H), out[1][0].data_ptr(), out[1][1].data_ptr())
+        assert rc == 0, lib.orbgpu_last_error(fe.handle)
+        assert lib.orbgpu_synchronize(fe.handle) == 0
+        pi, pd = out[0][0].cpu().numpy(), out[0][1].cpu().numpy()
+        gi, gd = out[1][0].cpu().numpy(), out[1][1].cpu().numpy()
+        assert np.array_equal(gi, pi) and np.array_equal(gd, pd), (th, ratio)
+        total = 0
+        for s, (nt, nf) in enumerate(sizes[:3] + sizes[5:]):          # the oracle on the small segments and one large one
+            s = s if s < 3 else 5
+            ts, fs = slice(s * cap, s * cap + nt), slice(s * cap, s * cap + nf)
+            omf, omd = oracle.snn_match(to_desc[ts], from_desc[fs], th, ratio, to_xy=to_xy[ts], to_window=win[ts],
+                                        to_min_level=lmin[ts], to_max_level=lmax[ts], to_active=active[ts],
+                                        from_xy=from_xy[fs], from_level=from_lv[fs])
+            assert np.array_equal(gi[ts], omf), (s, th, ratio)
+            sel = omf >= 0
+            assert np.array_equal(gd.view(np.uint32)[ts][sel], omd[sel])
+            total += int(sel.sum())
+        assert total > 100

@@ -630,3 +630,41 @@ def test_cosf_exposure_report(oracle):
     # descriptor bit changes: a 1-ulp change moves a tap coordinate by ~1e-6 px, far from every cvRound boundary
     assert n_angle_diff < 0.06 * n_kp
     assert n_bits <= 8
+
+
+def test_working_grid_lists_the_same_set(oracle):
+    """ListFeaturesInArea over the grid the reference means to have (PosInGrid's body behind the early return,
+    features.cpp:143-161) returns the same SET as over the degenerate grid it ships with, including for windows that reach
+    over the image border and keypoints outside the image; and the reference's known answer
+    (test/features/feature_tests.cpp:21-50) holds over it too."""
+    rng = np.random.default_rng(8)
+    W, H = 752.0, 480.0
+    n = 3000
+    kps = np.zeros(n, oracle.KP_DTYPE)
+    kps["x"] = rng.uniform(-30, W + 30, n)
+    kps["y"] = rng.uniform(-30, H + 30, n)
+    kps["level"] = rng.integers(0, 8, n)
+    xy = np.stack([kps["x"], kps["y"]], 1)
+    cs, items = oracle.assign_features_to_grid(xy, W, H)
+    assert cs[0] == 0 and cs[-1] == n and (np.diff(cs) >= 0).all()
+    assert sorted(items.tolist()) == list(range(n))
+    for c in np.flatnonzero(np.diff(cs) > 1)[:200]:
+        assert (np.diff(items[cs[c]:cs[c + 1]]) > 0).all()            # push_back order
+    nonempty = 0
+    for _ in range(400):
+        px, py = rng.uniform(-50, W + 50), rng.uniform(-50, H + 50)
+        win = int(rng.integers(0, 140))
+        lmin, lmax = int(rng.integers(-1, 4)), int(rng.integers(-1, 8))
+        flat = oracle.list_features_in_area(kps, px, py, win, lmin, lmax)
+        grid = oracle.list_features_in_area_grid(xy, kps["level"], cs, items, W, H, px, py, win, lmin, lmax)
+        assert sorted(grid.tolist()) == flat.tolist()
+        nonempty += len(flat) > 0
+    assert nonempty > 150
+    # the reference's own fixture (test/features/feature_tests.cpp:21-50) over the working grid
+    pts = [(120, 62, 0), (20, 42, 1), (57, 259, 0), (185, 336, 2), (198, 78, 0), (1, 1, 0), (17, 451, 5),
+           (301, 42, 0), (510, 79, 1), (604, 21, 0), (632, 262, 0)]
+    xy11 = np.array([(x, y) for x, y, _ in pts], np.float64)
+    lv11 = np.array([l for _, _, l in pts], np.int32)
+    cs11, it11 = oracle.assign_features_to_grid(xy11, 640.0, 480.0)
+    q = lambda w, l0, l1: oracle.list_features_in_area_grid(xy11, lv11, cs11, it11, 640.0, 480.0, 190.0, 80.0, w, l0, l1)
+    assert len(q(10, 0, 2)) == 1 and len(q(10, 1, 2)) == 0 and sorted(q(100, 0, 2).tolist()) == [0, 4]
