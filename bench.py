@@ -44,6 +44,97 @@ def launch_ranks(n, argv):
         raise SystemExit(f"bench.py: rank exit codes {codes}")
 
 
+def projection_bench(lib, handle, g, d_kp, d_desc, n_kp, B, cap, W, H, dev, per_call):
+    """Search by projection over the B - 1 frame pairs of an extracted batch: radius multipliers 15 / 30 x
+    scale_factors_[level] truncated to size_t (features.cpp:82), levels [l - 1, l + 1], TH 100, ratio 0.9 / 0.8
+    (monocular_frame.cpp:285-310, :358-380).  Legs: one orbgpu_match_window_device call per pair (per_call), one
+    orbgpu_match_window_segments_device call for all pairs, and the same over the 64 x 48 search grid
+    (orbgpu_match_window_grid_segments_device); all asserted identical."""
+    import ctypes as C
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd._lib import WindowArgs
+
+    def check(rc):
+        if rc != 0:
+            raise RuntimeError(lib.orbgpu_last_error(handle).decode())
+
+    out = {}
+    kp64 = d_kp.view(torch.float64)                          # [B, cap, 4]: x, y, (angle | size), (level | reserved)
+    lvl = d_kp.view(torch.int32)[:, :, 6].contiguous()       # [B, cap]
+    xy = kp64[:, :, :2].contiguous()
+    scale_t = torch.tensor([g.scale[i] for i in range(g.levels)], dtype=torch.float64, device=dev)
+    lmin = torch.clamp(lvl - 1, min=0).contiguous()
+    lmax = (lvl + 1).contiguous()
+    p_idx = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    p_dist = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    nominal = 256 * 64 * 2.4e9 / 16
+    pairs = float(sum(int(n_kp[t - 1]) * int(n_kp[t]) for t in range(1, B)))
+    seg = np.zeros(B - 1, _lib.SEGMENT_DTYPE)
+    for t in range(1, B):
+        seg[t - 1] = ((t - 1) * cap, int(n_kp[t - 1]), t * cap, int(n_kp[t]))
+    d_seg = torch.from_numpy(seg.view(np.int32).reshape(-1, 4)).to(dev)
+    max_to, max_from = int(n_kp[:B - 1].max()), int(n_kp[1:].max())
+    for mult, ratio in ((15.0, 0.9), (30.0, 0.8)):
+        win = (mult * scale_t[lvl.clamp(0, g.levels - 1).long()]).to(torch.int64).contiguous()   # truncation
+        entry = {"calls": B - 1, "predicated_pairs": pairs}
+        ab = WindowArgs(d_desc.data_ptr(), xy.data_ptr(), win.data_ptr(), lmin.data_ptr(), lmax.data_ptr(), None, B * cap,
+                        d_desc.data_ptr(), xy.data_ptr(), lvl.data_ptr(), B * cap, 100, ratio)
+
+        def timed(fn):
+            best = None
+            for it in range(4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn()
+                check(lib.orbgpu_synchronize(handle))
+                dt_ = time.perf_counter() - t1
+                best = dt_ if best is None or it == 1 else min(best, dt_)       # the first pass warms scratch
+            return best
+
+        b_idx = torch.full((B * cap,), -1, dtype=torch.int32, device=dev)
+        b_dist = torch.zeros(B * cap, dtype=torch.int32, device=dev)
+        bbest = timed(lambda: check(lib.orbgpu_match_window_segments_device(
+            handle, C.byref(ab), d_seg.data_ptr(), B - 1, max_to, b_idx.data_ptr(), b_dist.data_ptr())))
+        g_idx = torch.full((B * cap,), -1, dtype=torch.int32, device=dev)
+        g_dist = torch.zeros(B * cap, dtype=torch.int32, device=dev)
+        gbest = timed(lambda: check(lib.orbgpu_match_window_grid_segments_device(
+            handle, C.byref(ab), d_seg.data_ptr(), B - 1, max_to, max_from, float(W), float(H), g_idx.data_ptr(),
+            g_dist.data_ptr())))
+        same_grid = bool(torch.equal(b_idx, g_idx) and torch.equal(b_dist, g_dist))
+        assert same_grid, "search by projection over the grid differs from the plain scan"
+        if per_call:
+            calls = []
+            for t in range(1, B):
+                a = WindowArgs(d_desc[t - 1].data_ptr(), xy[t - 1].data_ptr(), win[t - 1].data_ptr(), lmin[t - 1].data_ptr(),
+                               lmax[t - 1].data_ptr(), None, int(n_kp[t - 1]), d_desc[t].data_ptr(), xy[t].data_ptr(),
+                               lvl[t].data_ptr(), int(n_kp[t]), 100, ratio)
+                calls.append((a, p_idx[t].data_ptr(), p_dist[t].data_ptr()))
+
+            def run_calls():
+                for a, pi, pd in calls:
+                    check(lib.orbgpu_match_window_device(handle, C.byref(a), pi, pd))
+            best = timed(run_calls)
+            # segment t-1 writes the 'to' rows of frame t-1; the per-call results of pair t sit in p_idx[t]
+            same = all(torch.equal(b_idx.view(B, cap)[t - 1, :int(n_kp[t - 1])], p_idx[t, :int(n_kp[t - 1])])
+                       for t in range(1, B))
+            assert same, "batched search by projection differs from the per-call results"
+            entry.update({"ms": round(best * 1e3, 3), "predicated_pairs_per_s": round(pairs / best, 1),
+                          "frac_of_nominal_popcount_peak": round(pairs / best / nominal, 5)})
+        entry["matches_first_8_pairs"] = int(sum(int((b_idx.view(B, cap)[t - 1, :int(n_kp[t - 1])] >= 0).sum().item())
+                                                 for t in range(1, min(B, 9))))
+        entry["one_call_for_all_pairs"] = {"ms": round(bbest * 1e3, 3), "predicated_pairs_per_s": round(pairs / bbest, 1),
+                                           "frac_of_nominal_popcount_peak": round(pairs / bbest / nominal, 5),
+                                           "identical_to_per_call_results": True if per_call else None}
+        entry["one_call_over_search_grid"] = {"ms": round(gbest * 1e3, 3), "predicated_pairs_per_s": round(pairs / gbest, 1),
+                                              "identical_to_plain_scan": same_grid,
+                                              "note": "64 x 48 grid of features.cpp:127-161 as a device index; includes "
+                                                      "building the grids of all frames; pairs/s counts the pairs the "
+                                                      "plain scan evaluates"}
+        out[f"radius_{int(mult)}_ratio_{ratio}"] = entry
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -375,6 +466,9 @@ def main():
                 "stage_ms": {k: round(float(v), 4) for k, v in lst.items() if k != "total"},
                 "keypoints_mean": round(float(l_n.float().mean().item()), 1),
                 "link_matches_mean": round(float(l_nm.float().mean().item()), 1)}
+            if not args.no_projection:
+                large[f"{lw}x{lh}"]["projection_match"] = projection_bench(
+                    lib, lfe.handle, lg, l_kp, l_desc, l_n.cpu().numpy(), lb, lcap, lw, lh, dev, per_call=False)
             lfe.close()
             del l_imgs, l_kp, l_desc, l_m, l_d
             torch.cuda.empty_cache()
@@ -386,66 +480,7 @@ def main():
     # orbgpu_match_window_device call per frame pair, as the reference makes one MatchWithIterators call per frame.
     projection = {}
     if not args.no_projection and n_pairs > 0:
-        from orb_slam3_amd._lib import WindowArgs
-        kp64 = d_kp.view(torch.float64)                          # [B, cap, 4]: x, y, (angle | size), (level | reserved)
-        lvl = d_kp.view(torch.int32)[:, :, 6].contiguous()       # [B, cap]
-        xy = kp64[:, :, :2].contiguous()
-        scale_t = torch.tensor([g.scale[i] for i in range(g.levels)], dtype=torch.float64, device=dev)
-        lmin = torch.clamp(lvl - 1, min=0).contiguous()
-        lmax = (lvl + 1).contiguous()
-        p_idx = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-        p_dist = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-        for mult, ratio in ((15.0, 0.9), (30.0, 0.8)):
-            win = (mult * scale_t[lvl.clamp(0, g.levels - 1).long()]).to(torch.int64).contiguous()   # truncation
-            torch.cuda.synchronize()
-            calls = []
-            for t in range(1, B):
-                a = WindowArgs(d_desc[t - 1].data_ptr(), xy[t - 1].data_ptr(), win[t - 1].data_ptr(), lmin[t - 1].data_ptr(),
-                               lmax[t - 1].data_ptr(), None, int(n_kp[t - 1]), d_desc[t].data_ptr(), xy[t].data_ptr(),
-                               lvl[t].data_ptr(), int(n_kp[t]), 100, ratio)
-                calls.append((a, p_idx[t].data_ptr(), p_dist[t].data_ptr()))
-            best = None
-            for it in range(3):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for a, pi, pd in calls:
-                    check(lib.orbgpu_match_window_device(fe.handle, C.byref(a), pi, pd))
-                check(lib.orbgpu_synchronize(fe.handle))
-                dt_ = time.perf_counter() - t1
-                best = dt_ if best is None else min(best, dt_)
-            pairs = float(sum(int(n_kp[t - 1]) * int(n_kp[t]) for t in range(1, B)))
-            nominal = 256 * 64 * 2.4e9 / 16
-            matched = int(sum(int((p_idx[t, :int(n_kp[t - 1])] >= 0).sum().item()) for t in range(1, min(B, 9))))
-            per_call_idx = p_idx.clone()
-            # the same 255 searches as ONE orbgpu_match_window_segments_device call (what an offline batch uses)
-            seg = np.zeros(B - 1, _lib.SEGMENT_DTYPE)
-            for t in range(1, B):
-                seg[t - 1] = ((t - 1) * cap, int(n_kp[t - 1]), t * cap, int(n_kp[t]))
-            d_seg = torch.from_numpy(seg.view(np.int32).reshape(-1, 4)).to(dev)
-            b_idx = torch.full((B * cap,), -1, dtype=torch.int32, device=dev)
-            b_dist = torch.zeros(B * cap, dtype=torch.int32, device=dev)
-            ab = WindowArgs(d_desc.data_ptr(), xy.data_ptr(), win.data_ptr(), lmin.data_ptr(), lmax.data_ptr(), None, B * cap,
-                            d_desc.data_ptr(), xy.data_ptr(), lvl.data_ptr(), B * cap, 100, ratio)
-            bbest = None
-            for it in range(4):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                check(lib.orbgpu_match_window_segments_device(fe.handle, C.byref(ab), d_seg.data_ptr(), B - 1,
-                                                              int(n_kp[:B - 1].max()), b_idx.data_ptr(), b_dist.data_ptr()))
-                check(lib.orbgpu_synchronize(fe.handle))
-                dt_ = time.perf_counter() - t1
-                bbest = dt_ if bbest is None or it == 1 else min(bbest, dt_)
-            # segment t-1 writes the 'to' rows of frame t-1; the per-call results of pair t sit in p_idx[t]
-            same = all(torch.equal(b_idx.view(B, cap)[t - 1, :int(n_kp[t - 1])], per_call_idx[t, :int(n_kp[t - 1])])
-                       for t in range(1, B))
-            assert same, "batched search by projection differs from the per-call results"
-            projection[f"radius_{int(mult)}_ratio_{ratio}"] = {
-                "calls": B - 1, "ms": round(best * 1e3, 3), "predicated_pairs": pairs,
-                "predicated_pairs_per_s": round(pairs / best, 1), "frac_of_nominal_popcount_peak": round(pairs / best / nominal, 5),
-                "matches_first_8_pairs": matched,
-                "one_call_for_all_pairs": {"ms": round(bbest * 1e3, 3), "predicated_pairs_per_s": round(pairs / bbest, 1),
-                                           "frac_of_nominal_popcount_peak": round(pairs / bbest / nominal, 5),
-                                           "identical_to_per_call_results": same}}
+        projection = projection_bench(lib, fe.handle, g, d_kp, d_desc, n_kp, B, cap, W, H, dev, per_call=True)
 
     host_path = {}
     if args.host_path and world == 1:
