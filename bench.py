@@ -415,6 +415,30 @@ def main():
                     "frac_of_measured_peak": round(n * n / bf / peak_measured, 4),
                     "frac_of_nominal_peak": round(n * n / bf / nominal, 4),
                     "n_matched": n_matched}
+        # exploratory engine: the same call with the distances on the i8 matrix cores; popcount
+        # stays the contract path and the numbers above.  Results asserted identical.
+        pi, pd = di.clone(), dd.clone()
+        check(lib.orbgpu_set_bruteforce_engine(fe.handle, _lib.ENGINE_MFMA_I8))
+        mt = []
+        for it in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            check(lib.orbgpu_match_bruteforce_device(fe.handle, dt.data_ptr(), n, df.data_ptr(), n, 50, 0.9,
+                                                     di.data_ptr(), dd.data_ptr()))
+            check(lib.orbgpu_synchronize(fe.handle))
+            mt.append(time.perf_counter() - t1)
+        check(lib.orbgpu_set_bruteforce_engine(fe.handle, _lib.ENGINE_POPCOUNT))
+        mf = min(mt[1:])
+        same = bool(torch.equal(pi, di) and torch.equal(pd[pi >= 0], dd[pi >= 0]))
+        assert same, "the MFMA engine's matches differ from the popcount engine's"
+        mfma_peak = 256 * 4 * (32 * 32 * 32 / 32.0) * 2.4e9 / 256    # CUs x SIMDs x MACs/clk of 32x32x32 i8 / 256 dims
+        matching["mfma_i8_exploration"] = {
+            "bruteforce_ms": round(mf * 1e3, 3), "pairs_per_s": round(n * n / mf, 1),
+            "speedup_over_popcount": round(bf / mf, 2), "identical_to_popcount_results": same,
+            "frac_of_nominal_popcount_peak": round(n * n / mf / nominal, 4),
+            "frac_of_i8_mfma_peak": round(n * n / mf / mfma_peak, 4),
+            "note": "descriptor bits as +1/-1 bytes, dot = 256 - 2*distance in v_mfma_i32_32x32x32_i8; tiles with no "
+                    "candidate within the threshold skip the best/second update"}
 
     # ---- BASELINE.json configs[2]: large images, extraction throughput vs the HBM roofline (informational) -------
     large = {}

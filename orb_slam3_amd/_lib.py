@@ -60,6 +60,7 @@ class BowScoreArgs(C.Structure):
                 ("kf_counts", C.c_void_p), ("scoring", C.c_int32), ("reserved", C.c_int32)]
 
 
+ENGINE_POPCOUNT, ENGINE_MFMA_I8 = 0, 1
 SEGMENT_DTYPE = np.dtype([("to_begin", "<i4"), ("to_count", "<i4"), ("from_begin", "<i4"), ("from_count", "<i4")])
 KP_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("angle", "<f4"), ("size", "<i4"), ("level", "<i4"), ("reserved", "<i4")])
 assert KP_DTYPE.itemsize == 32
@@ -67,7 +68,7 @@ assert KP_DTYPE.itemsize == 32
 # every symbol include/orbgpu.h declares (the inline orbgpu_hamming256 aside)
 EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_geometry", "orbgpu_stream",
            "orbgpu_synchronize", "orbgpu_set_stream", "orbgpu_set_batch_slices", "orbgpu_wait_event", "orbgpu_record_event", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
-           "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_bruteforce_noalloc_device",
+           "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_bruteforce_noalloc_device", "orbgpu_set_bruteforce_engine",
            "orbgpu_match_window",
            "orbgpu_match_window_device", "orbgpu_match_window_segments_device", "orbgpu_grid_build_device",
            "orbgpu_match_window_grid_segments_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
@@ -110,6 +111,7 @@ def load():
         "orbgpu_match_bruteforce": (i32, [vp, vp, i32, vp, i32, u32, dbl, vp, vp]),
         "orbgpu_match_bruteforce_device": (i32, [vp, vp, i32, vp, i32, u32, dbl, vp, vp]),
         "orbgpu_match_bruteforce_noalloc_device": (i32, [vp, vp, i32, vp, i32, u32, dbl, vp, vp]),
+        "orbgpu_set_bruteforce_engine": (i32, [vp, i32]),
         "orbgpu_match_window": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_window_device": (i32, [vp, C.POINTER(WindowArgs), vp, vp]),
         "orbgpu_match_window_segments_device": (i32, [vp, C.POINTER(WindowArgs), vp, i32, i32, vp, vp]),

@@ -745,7 +745,7 @@ static int match_device_locked(orbgpu_ctx *ctx, const orbgpu_window_args &a, int
   }
   int rc = ensure_match_scratch(ctx, match_scratch_size(a.n_to, a.n_from));
   if (rc) return rc;
-  launch_match(ctx, a, d_from_idx, d_dist, ctx->d_match_scratch);
+  launch_match(ctx, a, d_from_idx, d_dist, ctx->d_match_scratch, 0x7fffffff, ctx->bruteforce_mfma);
   HIP_TRY(hipGetLastError());
   return ORBGPU_OK;
 }
@@ -761,6 +761,15 @@ int orbgpu_match_bruteforce_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, in
   a.to_desc = d_to_desc; a.n_to = n_to; a.from_desc = d_from_desc; a.n_from = n_from;
   a.threshold = threshold; a.ratio = ratio;
   return match_device_locked(ctx, a, d_from_idx_per_to, d_dist);
+}
+
+int orbgpu_set_bruteforce_engine(orbgpu_ctx *ctx, int32_t engine) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  if (engine != ORBGPU_ENGINE_POPCOUNT && engine != ORBGPU_ENGINE_MFMA_I8)
+    return fail(ctx, ORBGPU_E_INVALID, "unknown brute-force engine");
+  ctx->bruteforce_mfma = engine == ORBGPU_ENGINE_MFMA_I8;
+  return ORBGPU_OK;
 }
 
 int orbgpu_match_bruteforce_noalloc_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, int32_t n_to,

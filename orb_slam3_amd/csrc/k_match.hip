@@ -153,6 +153,114 @@ __device__ __forceinline__ void merge_keys(unsigned &best, unsigned &second, uns
   second = min(min(second, s2), hi);
 }
 
+// ------------------------------------------------------------------------------------------------
+// EXPLORATORY (the popcount kernels above stay the contract path): brute-force Hamming on the
+// matrix cores.  With descriptor bits expanded to bytes +1 / -1, dot(a, b) = 256 - 2 * hamming(a, b), exact in
+// v_mfma_i32_32x32x32_i8 (8 of them per 32 x 32 tile of pairs).  A workgroup of 4 waves owns 512 'to' rows (each wave
+// MF_T tiles of 32, expanded once into registers as the B operand); the 'from' rows of its chunk stream through LDS 32 at
+// a time, expanded by the workgroup once per step (A operand).  In the 32 x 32 result a lane holds one 'to' column and
+// 16 'from' rows, so best / second stay per lane; the two lane halves of a column merge at the end.  Only candidates
+// within the threshold can take part in the ratio test (second_nearest_neighbor_matcher.hpp:47-48), so a tile whose
+// largest dot product is below 256 - 2 * TH is dropped after an 8-instruction maximum -- for descriptor sets with few
+// near pairs the epilogue all but disappears and the kernel runs at the rate of the MFMA pipe.
+constexpr int MF_T = 4;  // 'to' tiles of 32 rows per wave
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// 4 descriptor bits -> 4 bytes, +1 (0x01) for a set bit, -1 (0xff) for a clear one
+__device__ __forceinline__ unsigned expand_pm1(unsigned w, int q) {
+  const unsigned nib = (w >> (4 * q)) & 15u;
+  const unsigned t = __umul24(nib, 0x204081u) & 0x01010101u;  // bit k -> byte k
+  const unsigned m = t ^ 0x01010101u;
+  return t | ((m << 8) - m);  // m * 255: 0xff in the bytes of clear bits
+}
+
+__global__ __launch_bounds__(256) void k_snn_mfma(orbgpu_window_args a, int chunk, uint2 *__restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) unsigned abuf[2][8 * 2 * 32 * 4];  // [buffer][m][h][row][4 dwords]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int j0 = blockIdx.y * chunk, j1 = min(j0 + chunk, a.n_from);
+  const int to0 = (blockIdx.x * 4 + wv) * (MF_T * 32);
+  const unsigned *__restrict__ td = reinterpret_cast<const unsigned *>(a.to_desc);
+  const unsigned *__restrict__ fd = reinterpret_cast<const unsigned *>(a.from_desc);
+
+  // B operand: lane (col, h) of MFMA m holds dimensions [32 m + 16 h, + 16) of 'to' row col of the tile
+  v4i bfrag[MF_T][8];
+#pragma unroll
+  for (int t = 0; t < MF_T; t++) {
+    const int row = min(to0 + t * 32 + col, a.n_to - 1);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const unsigned w = td[(size_t)row * 8 + m] >> (16 * h);
+      bfrag[t][m] = v4i{(int)expand_pm1(w, 0), (int)expand_pm1(w, 1), (int)expand_pm1(w, 2), (int)expand_pm1(w, 3)};
+    }
+  }
+  unsigned best[MF_T], second[MF_T];
+#pragma unroll
+  for (int t = 0; t < MF_T; t++) best[t] = second[t] = KEY_NONE;
+  const int dmin = 256 - 2 * (int)a.threshold;  // dot >= dmin  <=>  distance <= threshold
+
+  // staging: thread (r = tid & 31, m = tid >> 5) expands dword m of 'from' row r of the step
+  const int sr = tid & 31, sm = tid >> 5;
+  auto load_raw = [&](int jb) {
+    const int j = jb + sr;
+    return j < j1 ? fd[(size_t)j * 8 + sm] : 0u;
+  };
+  auto store_exp = [&](int buf, unsigned w) {
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+      const unsigned x = w >> (16 * hh);
+      uint4 o = make_uint4(expand_pm1(x, 0), expand_pm1(x, 1), expand_pm1(x, 2), expand_pm1(x, 3));
+      *reinterpret_cast<uint4 *>(&abuf[buf][((sm * 2 + hh) * 32 + sr) * 4]) = o;
+    }
+  };
+  store_exp(0, load_raw(j0));
+  __syncthreads();
+  int buf = 0;
+  for (int jb = j0; jb < j1; jb += 32, buf ^= 1) {
+    const bool more = jb + 32 < j1;
+    unsigned raw = 0;
+    if (more) raw = load_raw(jb + 32);
+    v16i acc[MF_T];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const uint4 av = *reinterpret_cast<const uint4 *>(&abuf[buf][((m * 2 + h) * 32 + col) * 4]);
+      const v4i af = v4i{(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+#pragma unroll
+      for (int t = 0; t < MF_T; t++) {
+        if (m == 0) acc[t] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bfrag[t][m], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < MF_T; t++) {
+      int mx = acc[t][0];
+#pragma unroll
+      for (int r = 1; r < 16; r++) mx = max(mx, acc[t][r]);
+      if (__ballot(mx >= dmin)) {
+        // key = distance << 23 | j with distance = (256 - dot) / 2: (256 - dot) << 22 + j
+        const unsigned cb = (1u << 30) + (unsigned)(jb + 4 * h);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int roff = (r & 3) + 8 * (r >> 2);  // C/D layout: row = (reg & 3) + 8 (reg >> 2) + 4 h
+          unsigned key = (unsigned)__mul24(acc[t][r], -(1 << 22)) + cb + (unsigned)roff;
+          key = (jb + 4 * h + roff < j1) ? key : KEY_NONE;
+          second[t] = umed3(best[t], key, second[t]);
+          best[t] = min(best[t], key);
+        }
+      }
+    }
+    if (more) store_exp(buf ^ 1, raw);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < MF_T; t++) {
+    merge_keys(best[t], second[t], __shfl_xor(best[t], 32), __shfl_xor(second[t], 32));
+    const int row = to0 + t * 32 + col;
+    if (h == 0 && row < a.n_to) partial[(size_t)blockIdx.y * a.n_to + row] = make_uint2(best[t], second[t]);
+  }
+}
+
 // ratio test of second_nearest_neighbor_matcher.hpp:57 on packed keys; returns the 'from' index or -1
 __device__ __forceinline__ int snn_accept(unsigned best, unsigned second, unsigned threshold, double ratio,
                                           unsigned &dist) {
@@ -1166,9 +1274,17 @@ size_t match_scratch_size(int n_to, int n_from) {
 }
 
 void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a, int *d_from_idx, unsigned *d_dist, void *scratch,
-                  int max_chunks) {
+                  int max_chunks, bool mfma) {
   int chunk;
-  const int n_chunks = pick_chunks(a.n_to, a.n_from, chunk, max_chunks);
+  int n_chunks = pick_chunks(a.n_to, a.n_from, chunk, max_chunks);
+  if (mfma && !a.to_xy) {
+    // 512 'to' rows per workgroup: about 1024 workgroups, chunks a multiple of the 32-row step; never more chunks than
+    // the popcount path would use (the scratch is sized for those)
+    const int to_blocks = (a.n_to + 511) / 512;
+    const int want = std::max(1, std::min(n_chunks, (1024 + to_blocks - 1) / to_blocks));
+    chunk = (((a.n_from + want - 1) / want) + 31) & ~31;
+    n_chunks = (a.n_from + chunk - 1) / chunk;
+  }
   unsigned long long *claim = reinterpret_cast<unsigned long long *>(scratch);
   uint2 *partial = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(scratch) +
                                              (((size_t)a.n_from * sizeof(unsigned long long) + 255) & ~(size_t)255));
@@ -1176,6 +1292,11 @@ void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a, int *d_from_
   if (a.to_xy) {
     dim3 grid((a.n_to + 255) / 256, n_chunks);
     hipLaunchKernelGGL((k_snn_partial<true, 1>), grid, dim3(256), 0, c->stream, a, chunk, partial);
+  } else if (mfma) {
+    orbgpu_window_args b = a;
+    b.threshold = std::min(a.threshold, 256u);
+    dim3 grid((a.n_to + 511) / 512, n_chunks);
+    hipLaunchKernelGGL(k_snn_mfma, grid, dim3(256), 0, c->stream, b, chunk, partial);
   } else if (a.n_to >= 16384) {
     dim3 grid((a.n_to + 511) / 512, n_chunks);
     hipLaunchKernelGGL((k_snn_partial<false, 2>), grid, dim3(256), 0, c->stream, a, chunk, partial);

@@ -147,6 +147,7 @@ struct orbgpu_ctx {
                                        // [7], [8] bracket the blur on its own stream, [9] = all slices joined
   int ev_head = 0, ev_pending = 0;
   bool ev_full[ORBGPU_EV_SETS]{};      // that set holds every stage boundary, not only the FAST kernel's and the total
+  bool bruteforce_mfma = false;  // exploratory engine of the brute-force matcher (orbgpu_set_bruteforce_engine)
   bool stage_timing = false;           // record every stage boundary (each event costs a few microseconds between kernels)
   float stage_ms[7]{};
   int last_frames = 0;
@@ -199,7 +200,7 @@ size_t quadtree_node_bytes(int node_cap);
 size_t match_scratch_size(int n_to, int n_from);
 // scratch holds match_scratch_size() bytes, or -- with max_chunks limiting the split of the 'from' range -- less
 void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a /* device pointers; to_xy==NULL => brute force */,
-                  int *d_from_idx, unsigned *d_dist, void *scratch, int max_chunks = 0x7fffffff);
+                  int *d_from_idx, unsigned *d_dist, void *scratch, int max_chunks = 0x7fffffff, bool mfma = false);
 // fixed per-GPU scratch of orbgpu_match_bruteforce_noalloc_device (a __device__ array in k_match.hip)
 constexpr size_t ORBGPU_NOALLOC_SCRATCH_BYTES = 8u << 20;
 constexpr int ORBGPU_NOALLOC_MAX_DEVICES = 64;
