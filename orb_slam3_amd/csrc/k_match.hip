@@ -175,14 +175,19 @@ __device__ __forceinline__ unsigned expand_pm1(unsigned w, int q) {
   return t | ((m << 8) - m);  // m * 255: 0xff in the bytes of clear bits
 }
 
-__global__ __launch_bounds__(256) void k_snn_mfma(orbgpu_window_args a, int chunk, uint2 *__restrict__ partial) {
+// two waves per SIMD (256 registers each): the accumulators then live in VGPRs, where the threshold check can read them
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_snn_mfma(orbgpu_window_args a,
+                                                                                             int chunk,
+                                                                                             uint2 *__restrict__ partial) {
   __shared__ __attribute__((aligned(16))) unsigned abuf[2][8 * 2 * 32 * 4];  // [buffer][m][h][row][4 dwords]
+  __shared__ __attribute__((aligned(8))) uint2 lut[256];                       // byte -> its 8 bits as +1 / -1 bytes
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
   const int j0 = blockIdx.y * chunk, j1 = min(j0 + chunk, a.n_from);
   const int to0 = (blockIdx.x * 4 + wv) * (MF_T * 32);
   const unsigned *__restrict__ td = reinterpret_cast<const unsigned *>(a.to_desc);
   const unsigned *__restrict__ fd = reinterpret_cast<const unsigned *>(a.from_desc);
+  lut[tid] = make_uint2(expand_pm1(tid, 0), expand_pm1(tid, 1));
 
   // B operand: lane (col, h) of MFMA m holds dimensions [32 m + 16 h, + 16) of 'to' row col of the tile
   v4i bfrag[MF_T][8];
@@ -199,20 +204,18 @@ __global__ __launch_bounds__(256) void k_snn_mfma(orbgpu_window_args a, int chun
 #pragma unroll
   for (int t = 0; t < MF_T; t++) best[t] = second[t] = KEY_NONE;
   const int dmin = 256 - 2 * (int)a.threshold;  // dot >= dmin  <=>  distance <= threshold
+  __syncthreads();                              // lut
 
-  // staging: thread (r = tid & 31, m = tid >> 5) expands dword m of 'from' row r of the step
+  // staging: thread (r = tid & 31, m = tid >> 5) expands dword m of 'from' row r of the step through the table
   const int sr = tid & 31, sm = tid >> 5;
   auto load_raw = [&](int jb) {
     const int j = jb + sr;
     return j < j1 ? fd[(size_t)j * 8 + sm] : 0u;
   };
   auto store_exp = [&](int buf, unsigned w) {
-#pragma unroll
-    for (int hh = 0; hh < 2; hh++) {
-      const unsigned x = w >> (16 * hh);
-      uint4 o = make_uint4(expand_pm1(x, 0), expand_pm1(x, 1), expand_pm1(x, 2), expand_pm1(x, 3));
-      *reinterpret_cast<uint4 *>(&abuf[buf][((sm * 2 + hh) * 32 + sr) * 4]) = o;
-    }
+    const uint2 e0 = lut[w & 255u], e1 = lut[(w >> 8) & 255u], e2 = lut[(w >> 16) & 255u], e3 = lut[w >> 24];
+    *reinterpret_cast<uint4 *>(&abuf[buf][((sm * 2 + 0) * 32 + sr) * 4]) = make_uint4(e0.x, e0.y, e1.x, e1.y);
+    *reinterpret_cast<uint4 *>(&abuf[buf][((sm * 2 + 1) * 32 + sr) * 4]) = make_uint4(e2.x, e2.y, e3.x, e3.y);
   };
   store_exp(0, load_raw(j0));
   __syncthreads();
@@ -244,7 +247,8 @@ __global__ __launch_bounds__(256) void k_snn_mfma(orbgpu_window_args a, int chun
         for (int r = 0; r < 16; r++) {
           const int roff = (r & 3) + 8 * (r >> 2);  // C/D layout: row = (reg & 3) + 8 (reg >> 2) + 4 h
           unsigned key = (unsigned)__mul24(acc[t][r], -(1 << 22)) + cb + (unsigned)roff;
-          key = (jb + 4 * h + roff < j1) ? key : KEY_NONE;
+          // rows past the end of the chunk (staged as zero bytes); tested on the key so that the test stays in here
+          key = (key & ((1u << IDX_BITS) - 1u)) < (unsigned)j1 ? key : KEY_NONE;
           second[t] = umed3(best[t], key, second[t]);
           best[t] = min(best[t], key);
         }
@@ -1278,10 +1282,21 @@ void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a, int *d_from_
   int chunk;
   int n_chunks = pick_chunks(a.n_to, a.n_from, chunk, max_chunks);
   if (mfma && !a.to_xy) {
-    // 512 'to' rows per workgroup: about 1024 workgroups, chunks a multiple of the 32-row step; never more chunks than
-    // the popcount path would use (the scratch is sized for those)
+    // 512 'to' rows per workgroup, two workgroups per CU: the number of 'from' chunks that leaves the last round of
+    // 512 workgroups fullest (chunks a multiple of the 32-row step and at least 1024 rows; never more chunks than the
+    // popcount path would use -- the scratch is sized for those)
     const int to_blocks = (a.n_to + 511) / 512;
-    const int want = std::max(1, std::min(n_chunks, (1024 + to_blocks - 1) / to_blocks));
+    const int maxc = std::max(1, std::min(n_chunks, std::min(16, a.n_from / 1024)));
+    int want = 1;
+    double best_eff = 0.0;
+    for (int cc = 1; cc <= maxc; cc++) {
+      const int wg = to_blocks * cc;
+      const double eff = (double)wg / (((wg + 511) / 512) * 512.0);
+      if (eff > best_eff + 0.02) {
+        best_eff = eff;
+        want = cc;
+      }
+    }
     chunk = (((a.n_from + want - 1) / want) + 31) & ~31;
     n_chunks = (a.n_from + chunk - 1) / chunk;
   }
