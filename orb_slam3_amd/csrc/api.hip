@@ -350,6 +350,8 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     ctx->no_zero_copy = z && z[0] == '1';
     const char *lt = std::getenv("ORBGPU_STAGE_TIMING");  // 1: start with every stage boundary timed
     ctx->stage_timing = lt && lt[0] == '1';
+    const char *ls = std::getenv("ORBGPU_LINK_SCAN");  // 1: large-capacity frame links by the plain scan, not the grid
+    ctx->link_plain_scan = ls && ls[0] == '1';
     const char *o = std::getenv("ORBGPU_SLICES");  // tuning aid: slices per batch, 0 / unset = automatic
     ctx->n_slices = o ? std::atoi(o) : 0;
   }
@@ -948,9 +950,7 @@ int orbgpu_match_frames_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp, con
     return fail(ctx, ORBGPU_E_INVALID, "null argument");
   if (capacity >= (1 << 23)) return fail(ctx, ORBGPU_E_INVALID, "capacity must be below 2^23");
   HIP_TRY(hipSetDevice(ctx->device));
-  const int n_chunks = (capacity + 255) / 256;
-  const size_t bytes = (size_t)n_pairs * capacity * 8 + (size_t)n_pairs * n_chunks * capacity * 8 + 256;
-  int rc = ensure_match_scratch(ctx, bytes);
+  int rc = ensure_match_scratch(ctx, link_scratch_bytes(n_pairs, capacity));
   if (rc) return rc;
   launch_match_frames(ctx, d_kp, d_desc, d_n, capacity, d_to_frame, d_from_frame, n_pairs, window, threshold, ratio,
                       check_orientation, d_match, d_dist, d_n_matches);

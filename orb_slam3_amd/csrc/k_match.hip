@@ -432,18 +432,16 @@ struct GridBuildArgs {
   int *s_lv;
 };
 
-template <bool CURVE, bool GATHER>
-__device__ __forceinline__ void grid_build_body(const GridBuildArgs &a, const GridDims &g, int r, int *hist, int *cursor,
-                                                int *wsum) {
+// count rows, of which keep(i) take part; getxy(i) = position; emit(k, i): row i is the k-th of the binned order.
+// Returns the number of rows kept.  hist / cursor: GRID_BINS ints each, wsum: GB_THREADS / 64 + 1.
+template <bool CURVE, class GetXY, class Keep, class Emit>
+__device__ __forceinline__ int grid_build_core(int count, const GridDims &g, int *__restrict__ tmp, int *cell_start_r,
+                                               int *hist, int *cursor, int *wsum, GetXY getxy, Keep keep, Emit emit) {
   const int tid = threadIdx.x;
-  const int begin = a.ranges[r * a.range_stride + a.range_off], count = a.ranges[r * a.range_stride + a.range_off + 1];
-  const size_t out = (size_t)r * a.out_stride;
-  const double2 *__restrict__ xy = a.xy + begin;
-  int *__restrict__ tmp = a.tmp + out;
   for (int b = tid; b < GRID_BINS; b += GB_THREADS) hist[b] = 0;
   __syncthreads();
   auto bin_of = [&](int i) {
-    const double2 p = xy[i];
+    const double2 p = getxy(i);
     const int2 c = pos_in_grid(p.x, p.y, g);
     if (!CURVE) return c.x * GRID_ROWS + c.y;
     // ordering only: a 64 x 64 lattice over the image, independent of the search grid
@@ -451,7 +449,8 @@ __device__ __forceinline__ void grid_build_body(const GridBuildArgs &a, const Gr
     y = y < g.h ? y : g.h;
     return hilbert64(c.x, min(63, (int)(y * (64.0 / g.h))));
   };
-  for (int i = tid; i < count; i += GB_THREADS) atomicAdd(&hist[bin_of(i)], 1);
+  for (int i = tid; i < count; i += GB_THREADS)
+    if (keep(i)) atomicAdd(&hist[bin_of(i)], 1);
   __syncthreads();
   // exclusive scan over the bins: GB_PER consecutive bins per thread, then the thread sums
   int local[GB_PER], sum = 0;
@@ -472,44 +471,61 @@ __device__ __forceinline__ void grid_build_body(const GridBuildArgs &a, const Gr
   for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
 #pragma unroll
   for (int k = 0; k < GB_PER; k++) cursor[tid * GB_PER + k] = base + local[k];
+  if (tid == GB_THREADS - 1) wsum[GB_THREADS / 64] = base + sum;
   __syncthreads();
-  if (!CURVE && a.cell_start) {
-    int *cs = a.cell_start + (size_t)r * (GRID_CELLS + 1);
-    for (int b = tid; b < GRID_CELLS; b += GB_THREADS) cs[b] = cursor[b];
-    if (tid == 0) cs[GRID_CELLS] = count;
+  const int total = wsum[GB_THREADS / 64];
+  if (!CURVE && cell_start_r) {
+    for (int b = tid; b < GRID_CELLS; b += GB_THREADS) cell_start_r[b] = cursor[b];
+    if (tid == 0) cell_start_r[GRID_CELLS] = total;
   }
   for (int i = tid; i < count; i += GB_THREADS) {
+    if (!keep(i)) continue;
     const int b = bin_of(i);
     tmp[atomicAdd(&cursor[b], 1)] = (int)(((unsigned)b << GRID_ITEM_BITS) | (unsigned)i);  // arrival order inside the bin
   }
   __syncthreads();  // tmp of this workgroup is complete; cursor[b] = end of bin b, cursor[b] - hist[b] = its start
-  for (int k = tid; k < count; k += GB_THREADS) {
+  for (int k = tid; k < total; k += GB_THREADS) {
     const unsigned e = (unsigned)tmp[k];
     const int b = (int)(e >> GRID_ITEM_BITS), i = (int)(e & ((1u << GRID_ITEM_BITS) - 1u));
     const int b1 = cursor[b], b0 = b1 - hist[b];
     int rank = 0;
     for (int q = b0; q < b1; q++) rank += (tmp[q] & ((1 << GRID_ITEM_BITS) - 1)) < i;
-    const size_t dst = out + b0 + rank;
-    a.items[dst] = i;
-    if (GATHER) {
-      a.s_desc[2 * dst] = a.desc[2 * (size_t)(begin + i)];
-      a.s_desc[2 * dst + 1] = a.desc[2 * (size_t)(begin + i) + 1];
-      a.s_xy[dst] = xy[i];
-      a.s_lv[dst] = a.level[begin + i];
-    }
+    emit(b0 + rank, i);
   }
+  return total;
+}
+
+template <bool CURVE, bool GATHER>
+__device__ __forceinline__ void grid_build_body(const GridBuildArgs &a, const GridDims &g, int r, int *hist, int *cursor,
+                                                int *wsum) {
+  const int begin = a.ranges[r * a.range_stride + a.range_off], count = a.ranges[r * a.range_stride + a.range_off + 1];
+  const size_t out = (size_t)r * a.out_stride;
+  const double2 *__restrict__ xy = a.xy + begin;
+  grid_build_core<CURVE>(
+      count, g, a.tmp + out, (!CURVE && a.cell_start) ? a.cell_start + (size_t)r * (GRID_CELLS + 1) : nullptr, hist, cursor,
+      wsum, [&](int i) { return xy[i]; }, [](int) { return true; },
+      [&](int k, int i) {
+        const size_t dst = out + k;
+        a.items[dst] = i;
+        if (GATHER) {
+          a.s_desc[2 * dst] = a.desc[2 * (size_t)(begin + i)];
+          a.s_desc[2 * dst + 1] = a.desc[2 * (size_t)(begin + i) + 1];
+          a.s_xy[dst] = xy[i];
+          a.s_lv[dst] = a.level[begin + i];
+        }
+      });
 }
 
 // the grid by itself (orbgpu_grid_build_device): grid = ranges
 __global__ __launch_bounds__(GB_THREADS) void k_grid_build(GridBuildArgs a, GridDims g) {
-  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64];
+  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64 + 1];
   grid_build_body<false, false>(a, g, blockIdx.x, hist, cursor, wsum);
 }
 
 // both sides of a batch of window searches in one launch: grid = (segments, 2); y = 0 bins the 'from' rows by cell and
 // gathers their copies, y = 1 orders the 'to' rows along the curve
 __global__ __launch_bounds__(GB_THREADS) void k_grid_build_pair(GridBuildArgs from, GridBuildArgs to, GridDims g) {
-  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64];
+  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64 + 1];
   if (blockIdx.y == 0)
     grid_build_body<false, true>(from, g, blockIdx.x, hist, cursor, wsum);
   else
@@ -533,41 +549,16 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // fetched 64 candidates at a time (one per lane, the next 64 in flight while these are evaluated) and every candidate is
 // broadcast with v_readlane: a scalar load per candidate would pay the full memory latency once per iteration (the
 // copies of a batch do not fit L2).
-__global__ __launch_bounds__(256) void k_snn_grid(orbgpu_window_args a, const orbgpu_segment *__restrict__ segs,
-                                                  GridDims g, int to_stride, int from_stride,
-                                                  const int *__restrict__ to_items, const int *__restrict__ cell_start,
-                                                  const int *__restrict__ s_idx, const uint4 *__restrict__ s_desc,
-                                                  const double2 *__restrict__ s_xy, const int *__restrict__ s_lv,
-                                                  int *__restrict__ from_idx, unsigned *__restrict__ dist,
-                                                  unsigned long long *__restrict__ claim) {
-  const orbgpu_segment sg = segs[blockIdx.y];
-  if ((int)(blockIdx.x * 256) >= sg.to_count) return;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  const bool live = p < sg.to_count;
-  const int li = to_items[(size_t)blockIdx.y * to_stride + min(p, sg.to_count - 1)];
-  const int i = sg.to_begin + li;
-  const uint4 *td = reinterpret_cast<const uint4 *>(a.to_desc) + 2 * (size_t)i;
-  const uint4 t0 = td[0], t1 = td[1];
-  const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-  ToWindow tw;
-  tw.x = a.to_xy[2 * (size_t)i];
-  tw.y = a.to_xy[2 * (size_t)i + 1];
-  tw.win = (double)a.to_window[i];
-  tw.lmin = a.to_min_level[i];
-  tw.lmax = a.to_max_level[i];
-  tw.check_levels = (tw.lmin > 0) || (tw.lmax >= 0);  // features.cpp:94
-  const bool active = live && !(a.to_active && !a.to_active[i]);
+// The scan of one wave over the binned 'from' rows of its frame (every lane of the 256-thread block must call it: it
+// holds two barriers).  flv == nullptr: the rows were filtered by level when they were binned.
+__device__ __forceinline__ void grid_scan(const ToWindow &tw, bool active, const unsigned (&t)[8], const GridDims &g,
+                                          const int *__restrict__ cs, const uint4 *__restrict__ fd,
+                                          const double2 *__restrict__ fxy, const int *__restrict__ flv,
+                                          const int *__restrict__ fid, unsigned &best, unsigned &second) {
   const int lane = threadIdx.x & 63;
   // features.cpp:91-92
   const int2 lo = pos_in_grid(tw.x - tw.win, tw.y - tw.win, g), hi = pos_in_grid(tw.x + tw.win, tw.y + tw.win, g);
   const int x0 = wave_min_i(active ? lo.x : GRID_COLS), x1 = wave_max_i(active ? hi.x : -1);
-  const int *__restrict__ cs = cell_start + (size_t)blockIdx.y * (GRID_CELLS + 1);
-  const size_t fb = (size_t)blockIdx.y * from_stride;
-  const uint4 *__restrict__ fd = s_desc + 2 * fb;
-  const double2 *__restrict__ fxy = s_xy + fb;
-  const int *__restrict__ flv = s_lv + fb;
-  const int *__restrict__ fid = s_idx + fb;
-  unsigned best = KEY_NONE, second = KEY_NONE;
   auto rl = [](unsigned v, int c) { return (unsigned)__builtin_amdgcn_readlane((int)v, c); };
   auto rld = [&](double v, int c) {
     const unsigned long long u = __double_as_longlong(v);
@@ -617,7 +608,7 @@ __global__ __launch_bounds__(256) void k_snn_grid(orbgpu_window_args a, const or
     const int k = __shfl(run0, col) + (f - (__shfl(run_end, col) - __shfl(run_len, col)));
     Cand c;
     c.xy = fxy[k];
-    c.lv = flv[k];
+    c.lv = flv ? flv[k] : 0;
     c.id = (unsigned)fid[k];
     c.a = fd[2 * k];
     c.b = fd[2 * k + 1];
@@ -642,6 +633,36 @@ __global__ __launch_bounds__(256) void k_snn_grid(orbgpu_window_args a, const or
       cur = nxt;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_snn_grid(orbgpu_window_args a, const orbgpu_segment *__restrict__ segs,
+                                                  GridDims g, int to_stride, int from_stride,
+                                                  const int *__restrict__ to_items, const int *__restrict__ cell_start,
+                                                  const int *__restrict__ s_idx, const uint4 *__restrict__ s_desc,
+                                                  const double2 *__restrict__ s_xy, const int *__restrict__ s_lv,
+                                                  int *__restrict__ from_idx, unsigned *__restrict__ dist,
+                                                  unsigned long long *__restrict__ claim) {
+  const orbgpu_segment sg = segs[blockIdx.y];
+  if ((int)(blockIdx.x * 256) >= sg.to_count) return;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < sg.to_count;
+  const int li = to_items[(size_t)blockIdx.y * to_stride + min(p, sg.to_count - 1)];
+  const int i = sg.to_begin + li;
+  const uint4 *td = reinterpret_cast<const uint4 *>(a.to_desc) + 2 * (size_t)i;
+  const uint4 t0 = td[0], t1 = td[1];
+  const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  ToWindow tw;
+  tw.x = a.to_xy[2 * (size_t)i];
+  tw.y = a.to_xy[2 * (size_t)i + 1];
+  tw.win = (double)a.to_window[i];
+  tw.lmin = a.to_min_level[i];
+  tw.lmax = a.to_max_level[i];
+  tw.check_levels = (tw.lmin > 0) || (tw.lmax >= 0);  // features.cpp:94
+  const bool active = live && !(a.to_active && !a.to_active[i]);
+  const int *__restrict__ cs = cell_start + (size_t)blockIdx.y * (GRID_CELLS + 1);
+  const size_t fb = (size_t)blockIdx.y * from_stride;
+  unsigned best = KEY_NONE, second = KEY_NONE;
+  grid_scan(tw, active, t, g, cs, s_desc + 2 * fb, s_xy + fb, s_lv + fb, s_idx + fb, best, second);
   if (!live) return;
   unsigned d = 0;
   int j = snn_accept(best, second, a.threshold, a.ratio, d);
@@ -868,6 +889,77 @@ __global__ __launch_bounds__(256) void k_link_resolve(const orbgpu_keypoint *__r
   const orbgpu_keypoint *kt = kp + (size_t)ft * capacity, *kf = kp + (size_t)ff * capacity;
   rotation_filter_block(
       n_to, m, [&](int i) { return kt[i].angle; }, [&](int j) { return kf[j].angle; }, nullptr, &n_matches[p]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linking over the search grid, for keypoint capacities beyond the fused kernel's LDS: replaces k_link_partial (the
+// finalize / resolve kernels above stay).  Build, grid = (pair, side): side 0 bins the level-0 'from' rows of the pair
+// (the only ones AreaToPointee lists, area_to_pointee.h:44-48) by cell and gathers their copies; side 1 orders the
+// visited 'to' rows (id 0 and the level-0 ids, area_to_iterator.h:24-43) along the Hilbert curve.
+__global__ __launch_bounds__(GB_THREADS) void k_link_grid_build(const orbgpu_keypoint *__restrict__ kp,
+                                                                const uint8_t *__restrict__ desc,
+                                                                const int *__restrict__ n_kp, int capacity,
+                                                                const int *__restrict__ to_frame,
+                                                                const int *__restrict__ from_frame, GridDims g,
+                                                                int *__restrict__ tmp, int *__restrict__ to_items,
+                                                                int *__restrict__ to_counts, int *__restrict__ cell_start,
+                                                                int *__restrict__ s_idx, uint4 *__restrict__ s_desc,
+                                                                double2 *__restrict__ s_xy) {
+  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64 + 1];
+  const int p = blockIdx.x;
+  const size_t out = (size_t)p * capacity;
+  if (blockIdx.y == 0) {
+    const int ff = from_frame[p], n = usable_count(n_kp[ff], capacity);
+    const orbgpu_keypoint *__restrict__ fk = kp + (size_t)ff * capacity;
+    const uint4 *__restrict__ fd = reinterpret_cast<const uint4 *>(desc + (size_t)ff * capacity * 32);
+    grid_build_core<false>(
+        n, g, tmp + out, cell_start + (size_t)p * (GRID_CELLS + 1), hist, cursor, wsum,
+        [&](int i) { return make_double2(fk[i].x, fk[i].y); }, [&](int i) { return fk[i].level == 0; },
+        [&](int k, int i) {
+          s_idx[out + k] = i;
+          s_desc[2 * (out + k)] = fd[2 * i];
+          s_desc[2 * (out + k) + 1] = fd[2 * i + 1];
+          s_xy[out + k] = make_double2(fk[i].x, fk[i].y);
+        });
+  } else {
+    const int ft = to_frame[p], n = usable_count(n_kp[ft], capacity);
+    const orbgpu_keypoint *__restrict__ tk = kp + (size_t)ft * capacity;
+    const int total = grid_build_core<true>(
+        n, g, tmp + (size_t)(gridDim.x + p) * capacity, nullptr, hist, cursor, wsum,
+        [&](int i) { return make_double2(tk[i].x, tk[i].y); }, [&](int i) { return i == 0 || tk[i].level == 0; },
+        [&](int k, int i) { to_items[out + k] = i; });
+    if (threadIdx.x == 0) to_counts[p] = total;
+  }
+}
+
+// grid: x = 256-row blocks of the pair's visited 'to' rows, y = pair.  partial[pair][capacity] was filled with KEY_NONE.
+__global__ __launch_bounds__(256) void k_link_grid(const orbgpu_keypoint *__restrict__ kp, const uint8_t *__restrict__ desc,
+                                                   int capacity, const int *__restrict__ to_frame, double window,
+                                                   GridDims g, const int *__restrict__ to_items,
+                                                   const int *__restrict__ to_counts, const int *__restrict__ cell_start,
+                                                   const int *__restrict__ s_idx, const uint4 *__restrict__ s_desc,
+                                                   const double2 *__restrict__ s_xy, uint2 *__restrict__ partial) {
+  const int p = blockIdx.y, nt = to_counts[p];
+  if ((int)(blockIdx.x * 256) >= nt) return;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const bool live = q < nt;
+  const size_t out = (size_t)p * capacity;
+  const int li = to_items[out + min(q, nt - 1)];
+  const size_t row = (size_t)to_frame[p] * capacity + li;
+  const orbgpu_keypoint k = kp[row];
+  const uint4 *td = reinterpret_cast<const uint4 *>(desc + row * 32);
+  const uint4 t0 = td[0], t1 = td[1];
+  const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  ToWindow tw;
+  tw.x = k.x;
+  tw.y = k.y;
+  tw.win = window;
+  tw.lmin = tw.lmax = 0;
+  tw.check_levels = false;  // the binned rows are the level-0 rows already
+  unsigned best = KEY_NONE, second = KEY_NONE;
+  grid_scan(tw, live, t, g, cell_start + (size_t)p * (GRID_CELLS + 1), s_desc + 2 * out, s_xy + out, nullptr, s_idx + out,
+            best, second);
+  if (live) partial[out + li] = make_uint2(best, second);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1361,6 +1453,11 @@ int match_noalloc_chunks(int n_to, int n_from) {
 
 size_t link_fused_lds_bytes(int capacity) { return (size_t)capacity * 24; }
 
+static GridDims grid_dims(double image_width, double image_height) {
+  // features.cpp:13-16
+  return GridDims{image_width, image_height, (double)GRID_COLS / image_width, (double)GRID_ROWS / image_height};
+}
+
 void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const uint8_t *d_desc, const int *d_n,
                          int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
                          unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,
@@ -1371,8 +1468,39 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
                        check_orientation, d_match, d_dist, d_n_matches);
     return;
   }
-  // very large keypoint capacities: three-kernel path through global scratch
-  // scratch: claim [pairs][capacity] u64, partial [pairs][chunks][capacity] uint2
+  const unsigned th = std::min(threshold, 256u);
+  if (capacity < (1 << GRID_ITEM_BITS) && !c->link_plain_scan) {
+    // large capacities: the level-0 rows of every pair binned by the 64 x 48 search grid laid over the context's image,
+    // then k_link_grid instead of the full predicated scan (same best / second per 'to' row; finalize / resolve as below)
+    const size_t rows = (size_t)n_pairs * capacity;
+    unsigned char *sp = reinterpret_cast<unsigned char *>(c->d_match_scratch);
+    auto take = [&](size_t bytes) {
+      void *q = sp;
+      sp += pad256(bytes);
+      return q;
+    };
+    unsigned long long *claim = reinterpret_cast<unsigned long long *>(take(rows * 8));
+    uint2 *partial = reinterpret_cast<uint2 *>(take(rows * 8));
+    int *tmp = reinterpret_cast<int *>(take(2 * rows * 4));
+    int *to_items = reinterpret_cast<int *>(take(rows * 4));
+    int *to_counts = reinterpret_cast<int *>(take((size_t)n_pairs * 4));
+    int *cell_start = reinterpret_cast<int *>(take((size_t)n_pairs * (GRID_CELLS + 1) * 4));
+    int *s_idx = reinterpret_cast<int *>(take(rows * 4));
+    double2 *s_xy = reinterpret_cast<double2 *>(take(rows * 16));
+    uint4 *s_desc = reinterpret_cast<uint4 *>(take(rows * 32));
+    (void)hipMemsetAsync(claim, 0xff, 2 * pad256(rows * 8), c->stream);  // claims and the (KEY_NONE, KEY_NONE) partials
+    const GridDims g = grid_dims((double)c->geom.lv[0].w, (double)c->geom.lv[0].h);
+    hipLaunchKernelGGL(k_link_grid_build, dim3(n_pairs, 2), dim3(GB_THREADS), 0, c->stream, d_kp, d_desc, d_n, capacity,
+                       d_to_frame, d_from_frame, g, tmp, to_items, to_counts, cell_start, s_idx, s_desc, s_xy);
+    hipLaunchKernelGGL(k_link_grid, dim3((capacity + 255) / 256, n_pairs), dim3(256), 0, c->stream, d_kp, d_desc, capacity,
+                       d_to_frame, (double)window, g, to_items, to_counts, cell_start, s_idx, s_desc, s_xy, partial);
+    hipLaunchKernelGGL(k_link_finalize, dim3((capacity + 255) / 256, n_pairs), dim3(256), 0, c->stream, d_kp, d_n,
+                       capacity, d_to_frame, d_from_frame, 1, partial, th, ratio, d_match, d_dist, claim);
+    hipLaunchKernelGGL(k_link_resolve, dim3(n_pairs), dim3(256), 0, c->stream, d_kp, d_n, capacity, d_to_frame,
+                       d_from_frame, claim, check_orientation, d_match, d_dist, d_n_matches);
+    return;
+  }
+  // the plain scan (ORBGPU_LINK_SCAN=1, or capacities of 2^20 and more): three kernels through global scratch
   const int chunk = 256;
   const int n_chunks = (capacity + chunk - 1) / chunk;
   unsigned long long *claim = reinterpret_cast<unsigned long long *>(c->d_match_scratch);
@@ -1381,11 +1509,19 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
   dim3 grid((capacity + 255) / 256, n_chunks, n_pairs);
   hipLaunchKernelGGL(k_link_partial, grid, dim3(256), 0, c->stream, d_kp, d_desc, d_n, capacity, d_to_frame,
                      d_from_frame, (double)window, chunk, n_chunks, partial);
-  const unsigned th = std::min(threshold, 256u);
   hipLaunchKernelGGL(k_link_finalize, dim3((capacity + 255) / 256, n_pairs), dim3(256), 0, c->stream, d_kp, d_n,
                      capacity, d_to_frame, d_from_frame, n_chunks, partial, th, ratio, d_match, d_dist, claim);
   hipLaunchKernelGGL(k_link_resolve, dim3(n_pairs), dim3(256), 0, c->stream, d_kp, d_n, capacity, d_to_frame,
                      d_from_frame, claim, check_orientation, d_match, d_dist, d_n_matches);
+}
+
+size_t link_scratch_bytes(int n_pairs, int capacity) {
+  const size_t rows = (size_t)n_pairs * capacity;
+  const size_t scan = rows * 8 + rows * 8 * (size_t)((capacity + 255) / 256) + 256;
+  const size_t grid = 2 * pad256(rows * 8) + pad256(2 * rows * 4) + pad256(rows * 4) + pad256((size_t)n_pairs * 4) +
+                      pad256((size_t)n_pairs * (GRID_CELLS + 1) * 4) + pad256(rows * 4) + pad256(rows * 16) +
+                      pad256(rows * 32) + 256;
+  return std::max(scan, grid);
 }
 
 // claim: one u64 per 'from' row of the concatenated arrays (scratch holds n_from_total of them)
@@ -1398,11 +1534,6 @@ void launch_match_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, con
   const dim3 grid((max_to_count + 255) / 256, n_segments);
   hipLaunchKernelGGL(k_snn_segments, grid, dim3(256), 0, c->stream, b, d_segs, d_from_idx, d_dist, claim);
   hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim);
-}
-
-static GridDims grid_dims(double image_width, double image_height) {
-  // features.cpp:13-16
-  return GridDims{image_width, image_height, (double)GRID_COLS / image_width, (double)GRID_ROWS / image_height};
 }
 
 size_t grid_build_scratch_bytes(int n_ranges, int max_count) { return (size_t)n_ranges * max_count * 4 + 256; }

@@ -147,6 +147,7 @@ struct orbgpu_ctx {
                                        // [7], [8] bracket the blur on its own stream, [9] = all slices joined
   int ev_head = 0, ev_pending = 0;
   bool ev_full[ORBGPU_EV_SETS]{};      // that set holds every stage boundary, not only the FAST kernel's and the total
+  bool link_plain_scan = false;   // ORBGPU_LINK_SCAN=1: large-capacity links by the plain predicated scan (comparison)
   bool bruteforce_mfma = false;  // exploratory engine of the brute-force matcher (orbgpu_set_bruteforce_engine)
   bool stage_timing = false;           // record every stage boundary (each event costs a few microseconds between kernels)
   float stage_ms[7]{};
@@ -207,6 +208,7 @@ constexpr int ORBGPU_NOALLOC_MAX_DEVICES = 64;
 hipError_t match_noalloc_init(int device);   // with `device` current; resolves the array's address on that GPU once
 void *match_noalloc_ptr(int device);
 int match_noalloc_chunks(int n_to, int n_from);
+size_t link_scratch_bytes(int n_pairs, int capacity);
 void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const uint8_t *d_desc, const int *d_n,
                          int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
                          unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,

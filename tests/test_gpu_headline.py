@@ -94,6 +94,73 @@ def test_large_64_frames_1080p(oracle):
     assert n.mean() > 4500 and nm.mean() > 300
 
 
+def test_large_capacity_link_grid_equals_plain_scan(oracle):
+    """Above the fused link kernel's capacity orbgpu_match_frames_device bins the level-0 rows by the 64 x 48 search grid
+    (k_link_grid); ORBGPU_LINK_SCAN=1 keeps the plain predicated scan.  Same matches, distances and counts, on pairs that
+    share frames in both roles (a frame linked to two others, and in both directions), with and without the rotation
+    filter, for windows of 100 and 30 px; one pair is checked against the oracle as well."""
+    import os
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    W, H, NF, B = 1920, 1080, 5000, 6
+    frames = synth.sequence(77, B, H, W)
+    dev = torch.device("cuda", 0)
+    pairs = [(1, 0), (2, 1), (2, 0), (0, 2), (5, 4), (3, 3)]
+    res = {}
+    for mode in ("grid", "scan"):
+        if mode == "scan":
+            os.environ["ORBGPU_LINK_SCAN"] = "1"
+        try:
+            fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_batch=B, max_features=NF)
+        finally:
+            os.environ.pop("ORBGPU_LINK_SCAN", None)
+        cap = fe.geometry(NF).keypoint_capacity
+        d_imgs = torch.from_numpy(frames).to(dev)
+        d_kp = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_to = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev)
+        d_from = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        assert lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr(), W * H, W, B, NF, d_kp.data_ptr(),
+                                               d_desc.data_ptr(), cap, d_n.data_ptr()) == 0
+        out = []
+        for window, check in ((100, 1), (100, 0), (30, 1)):
+            d_m = torch.full((len(pairs), cap), 9, dtype=torch.int32, device=dev)
+            d_d = torch.full((len(pairs), cap), 9, dtype=torch.int32, device=dev)
+            d_nm = torch.zeros(len(pairs), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            for rep in range(2):
+                rc = lib.orbgpu_match_frames_device(fe.handle, d_kp.data_ptr(), d_desc.data_ptr(), d_n.data_ptr(), cap,
+                                                    d_to.data_ptr(), d_from.data_ptr(), len(pairs), window, 50, 0.9, check,
+                                                    d_m.data_ptr(), d_d.data_ptr(), d_nm.data_ptr())
+                assert rc == 0, lib.orbgpu_last_error(fe.handle)
+            assert lib.orbgpu_synchronize(fe.handle) == 0
+            out.append((d_m.cpu().numpy(), d_d.cpu().numpy(), d_nm.cpu().numpy()))
+        res[mode] = out
+        if mode == "grid":
+            n = d_n.cpu().numpy()
+            kp = d_kp.cpu().numpy().view(_lib.KP_DTYPE).reshape(B, cap)
+            desc = d_desc.cpu().numpy()
+        fe.close()
+    for (gm, gd, gn), (sm, sd, sn) in zip(res["grid"], res["scan"]):
+        assert np.array_equal(gm, sm) and np.array_equal(gn, sn)
+        assert np.array_equal(gd[gm >= 0], sd[sm >= 0])
+    assert res["grid"][0][2].min() > 200                          # also the frame linked to itself
+    to, fr = pairs[2]
+    def ok(f):
+        k = np.zeros(n[f], oracle.KP_DTYPE)
+        for fld in ("x", "y", "angle", "size", "level"):
+            k[fld] = kp[f, :n[f]][fld]
+        return k, desc[f, :n[f]]
+    (kt, dt_), (kf, df_) = ok(to), ok(fr)
+    mf, _ = oracle.match_area(kt, dt_, kf, df_, 100, 50, 0.9)
+    mf, _ = oracle.orientation_validate(kt["angle"], kf["angle"], mf)
+    assert np.array_equal(res["grid"][0][0][2, :n[to]], mf)
+
+
 @pytest.mark.parametrize("n_to,n_from,settings", [
     (20011, 700, ((50, 0.9), (100, 0.8), (100, 0.6), (50, 1.0))),      # n_to not a multiple of 512, one 'from' chunk group
     (100000, 4000, ((50, 0.9), (100, 0.8))),
