@@ -286,16 +286,19 @@ int finish_pipeline(orbgpu_ctx *ctx) {
       acc[6] += elapsed(ev[0], ev[9]);
     }
     for (int i = 0; i < 7; i++) ctx->stage_ms[i] = acc[i] / (float)n;
-    if (*ctx->h_error_flag != 0) {
-      const int code = *ctx->h_error_flag;
-      *ctx->h_error_flag = 0;
-      HIP_TRY(hipMemsetAsync(ctx->d_error_flag, 0, sizeof(int), ctx->stream));
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      if (code == ORBGPU_ERR_OUT_CAPACITY)
-        return fail(ctx, ORBGPU_E_CAPACITY, "a frame has more keypoints than the caller's capacity: that frame was not written "
-                                            "(its entry of n_out holds the count it needs)");
-      return fail(ctx, ORBGPU_E_CAPACITY, "quadtree kernel capacity violation (code " + std::to_string(code) + ")");
-    }
+  }
+  if (*ctx->h_error_flag != 0) {  // copied back after every pipeline run and every grid matcher call
+    const int code = *ctx->h_error_flag;
+    *ctx->h_error_flag = 0;
+    HIP_TRY(hipMemsetAsync(ctx->d_error_flag, 0, sizeof(int), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (code == ORBGPU_ERR_OUT_CAPACITY)
+      return fail(ctx, ORBGPU_E_CAPACITY, "a frame has more keypoints than the caller's capacity: that frame was not written "
+                                          "(its entry of n_out holds the count it needs)");
+    if (code == ORBGPU_ERR_SEGMENT_SIZE)
+      return fail(ctx, ORBGPU_E_CAPACITY, "a segment or range holds more rows than the max_*_count the call was given: its "
+                                          "surplus rows were ignored");
+    return fail(ctx, ORBGPU_E_CAPACITY, "quadtree kernel capacity violation (code " + std::to_string(code) + ")");
   }
   return 0;
 }
@@ -856,6 +859,7 @@ int orbgpu_grid_build_device(orbgpu_ctx *ctx, const double *d_xy, const int32_t 
   if (rc) return rc;
   launch_grid_build(ctx, d_xy, d_ranges, n_ranges, max_count, image_width, image_height, d_cell_start, d_items,
                     ctx->d_match_scratch);
+  HIP_TRY(hipMemcpyAsync(ctx->h_error_flag, ctx->d_error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipGetLastError());
   return ORBGPU_OK;
 }
@@ -887,6 +891,7 @@ int orbgpu_match_window_grid_segments_device(orbgpu_ctx *ctx, const orbgpu_windo
   launch_match_grid_segments(ctx, *a, d_segments, n_segments, max_to_count, std::max(max_from_count, 1), a->n_from,
                              image_width, image_height, d_from_idx_per_to, reinterpret_cast<unsigned *>(d_dist),
                              ctx->d_match_scratch);
+  HIP_TRY(hipMemcpyAsync(ctx->h_error_flag, ctx->d_error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipGetLastError());
   return ORBGPU_OK;
 }

@@ -361,10 +361,11 @@ __global__ __launch_bounds__(256) void k_snn_segments(orbgpu_window_args a, cons
 __global__ __launch_bounds__(256) void k_snn_segments_resolve(const orbgpu_segment *__restrict__ segs,
                                                               int *__restrict__ from_idx,
                                                               const unsigned *__restrict__ dist,
-                                                              const unsigned long long *__restrict__ claim) {
+                                                              const unsigned long long *__restrict__ claim,
+                                                              int max_to) {
   const orbgpu_segment sg = segs[blockIdx.y];
   const int li = blockIdx.x * 256 + threadIdx.x;
-  if (li >= sg.to_count) return;
+  if (li >= min(sg.to_count, max_to)) return;
   const int i = sg.to_begin + li;
   const int j = from_idx[i];
   if (j >= 0 && claim[sg.from_begin + j] != (((unsigned long long)dist[i] << 32) | (unsigned)li)) from_idx[i] = -1;
@@ -430,6 +431,7 @@ struct GridBuildArgs {
   uint4 *s_desc;
   double2 *s_xy;
   int *s_lv;
+  int *error_flag;  // ORBGPU_ERR_SEGMENT_SIZE when a range is larger than out_stride (the surplus is ignored)
 };
 
 // count rows, of which keep(i) take part; getxy(i) = position; emit(k, i): row i is the k-th of the binned order.
@@ -498,7 +500,12 @@ __device__ __forceinline__ int grid_build_core(int count, const GridDims &g, int
 template <bool CURVE, bool GATHER>
 __device__ __forceinline__ void grid_build_body(const GridBuildArgs &a, const GridDims &g, int r, int *hist, int *cursor,
                                                 int *wsum) {
-  const int begin = a.ranges[r * a.range_stride + a.range_off], count = a.ranges[r * a.range_stride + a.range_off + 1];
+  const int begin = a.ranges[r * a.range_stride + a.range_off];
+  int count = a.ranges[r * a.range_stride + a.range_off + 1];
+  if (count > a.out_stride) {  // the caller's max count was too small: stay inside this range's rows and say so
+    if (threadIdx.x == 0 && a.error_flag) atomicExch(a.error_flag, ORBGPU_ERR_SEGMENT_SIZE);
+    count = a.out_stride;
+  }
   const size_t out = (size_t)r * a.out_stride;
   const double2 *__restrict__ xy = a.xy + begin;
   grid_build_core<CURVE>(
@@ -642,7 +649,8 @@ __global__ __launch_bounds__(256) void k_snn_grid(orbgpu_window_args a, const or
                                                   const double2 *__restrict__ s_xy, const int *__restrict__ s_lv,
                                                   int *__restrict__ from_idx, unsigned *__restrict__ dist,
                                                   unsigned long long *__restrict__ claim) {
-  const orbgpu_segment sg = segs[blockIdx.y];
+  orbgpu_segment sg = segs[blockIdx.y];
+  sg.to_count = min(sg.to_count, to_stride);  // larger: flagged by the build kernel
   if ((int)(blockIdx.x * 256) >= sg.to_count) return;
   const int p = blockIdx.x * 256 + threadIdx.x;
   const bool live = p < sg.to_count;
@@ -1533,7 +1541,7 @@ void launch_match_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, con
   b.threshold = std::min(a.threshold, 256u);
   const dim3 grid((max_to_count + 255) / 256, n_segments);
   hipLaunchKernelGGL(k_snn_segments, grid, dim3(256), 0, c->stream, b, d_segs, d_from_idx, d_dist, claim);
-  hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim);
+  hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim, INT_MAX);
 }
 
 size_t grid_build_scratch_bytes(int n_ranges, int max_count) { return (size_t)n_ranges * max_count * 4 + 256; }
@@ -1550,6 +1558,7 @@ void launch_grid_build(const orbgpu_ctx *c, const double *d_xy, const int *d_ran
   ga.tmp = reinterpret_cast<int *>(scratch);
   ga.items = d_items;
   ga.cell_start = d_cell_start;
+  ga.error_flag = c->d_error_flag;
   hipLaunchKernelGGL(k_grid_build, dim3(n_ranges), dim3(GB_THREADS), 0, c->stream, ga, grid_dims(image_width, image_height));
 }
 
@@ -1598,6 +1607,7 @@ void launch_match_grid_segments(const orbgpu_ctx *c, const orbgpu_window_args &a
   gf.s_desc = s_desc;
   gf.s_xy = s_xy;
   gf.s_lv = s_lv;
+  gf.error_flag = gt.error_flag = c->d_error_flag;
   gt.xy = reinterpret_cast<const double2 *>(a.to_xy);
   gt.ranges = ranges;
   gt.range_stride = 4;
@@ -1611,7 +1621,8 @@ void launch_match_grid_segments(const orbgpu_ctx *c, const orbgpu_window_args &a
   const dim3 grid((max_to_count + 255) / 256, n_segments);
   hipLaunchKernelGGL(k_snn_grid, grid, dim3(256), 0, c->stream, b, d_segs, g, max_to_count, max_from_count, to_items,
                      cell_start, s_idx, s_desc, s_xy, s_lv, d_from_idx, d_dist, claim);
-  hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim);
+  hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim,
+                     max_to_count);
 }
 
 size_t group_scratch_bytes(int n_from, int n_slots) { return (size_t)n_from * 8 + (size_t)n_slots * 8 + 256; }

@@ -78,6 +78,7 @@ __host__ __device__ inline unsigned pack_cand(int x, int y, int s) { return (uns
 struct CellEntry { int off, count; };  // segment of a (frame, level) candidate sub-pool
 
 // codes kernels leave in orbgpu_ctx::d_error_flag (1, 3: the quadtree kernel's own capacity checks)
+#define ORBGPU_ERR_SEGMENT_SIZE 17  // a grid range / segment is larger than the max count the call stated
 #define ORBGPU_ERR_OUT_CAPACITY 16  // a frame has more keypoints than the caller's `capacity`: it was not written
 
 // keypoints of a frame that consumers of orbgpu_extract_batch_device's output may read: a frame whose count exceeds the

@@ -466,3 +466,35 @@ def test_grid_window_segments_parity(oracle, fe, W, H, n_kp, radius):
             assert np.array_equal(gd.view(np.uint32)[ts][sel], omd[sel])
             total += int(sel.sum())
         assert total > 100
+
+
+def test_grid_segments_flags_an_understated_maximum(fe):
+    """max_from_count / max_to_count smaller than a segment: the library stays inside that segment's scratch rows and
+    orbgpu_synchronize reports ORBGPU_E_CAPACITY (the flag is cleared by that report)."""
+    import ctypes as C
+    import torch
+    from orb_slam3_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(2)
+    n = 500
+    dev = torch.device("cuda", 0)
+    desc = torch.from_numpy(rng.integers(0, 256, (n, 32), dtype=np.uint8)).to(dev)
+    xy = torch.from_numpy(rng.uniform(0, 600, (n, 2))).to(dev)
+    win = torch.full((n,), 20, dtype=torch.int64, device=dev)
+    lv = torch.zeros(n, dtype=torch.int32, device=dev)
+    segs = torch.tensor([[0, n, 0, n]], dtype=torch.int32, device=dev)
+    oi = torch.zeros(n, dtype=torch.int32, device=dev)
+    od = torch.zeros(n, dtype=torch.int32, device=dev)
+    a = _lib.WindowArgs(desc.data_ptr(), xy.data_ptr(), win.data_ptr(), lv.data_ptr(), lv.data_ptr(), None, n,
+                        desc.data_ptr(), xy.data_ptr(), lv.data_ptr(), n, 100, 0.9)
+    torch.cuda.synchronize()
+    for max_to, max_from in ((n, n - 100), (n - 100, n)):
+        assert lib.orbgpu_match_window_grid_segments_device(fe.handle, C.byref(a), segs.data_ptr(), 1, max_to, max_from,
+                                                            640.0, 480.0, oi.data_ptr(), od.data_ptr()) == 0
+        assert lib.orbgpu_synchronize(fe.handle) == _lib.E_CAPACITY
+        assert b"max_" in lib.orbgpu_last_error(fe.handle)
+        assert lib.orbgpu_synchronize(fe.handle) == 0
+    assert lib.orbgpu_match_window_grid_segments_device(fe.handle, C.byref(a), segs.data_ptr(), 1, n, n, 640.0, 480.0,
+                                                        oi.data_ptr(), od.data_ptr()) == 0
+    assert lib.orbgpu_synchronize(fe.handle) == 0
+    assert (oi.cpu().numpy() == np.arange(n)).all()              # every row finds itself
