@@ -353,6 +353,10 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     ctx->no_zero_copy = z && z[0] == '1';
     const char *lt = std::getenv("ORBGPU_STAGE_TIMING");  // 1: start with every stage boundary timed
     ctx->stage_timing = lt && lt[0] == '1';
+    const char *ws = std::getenv("ORBGPU_WINDOW_SCAN");  // 1: windowed searches by the plain scan, never the grid
+    ctx->window_plain_scan = ws && ws[0] == '1';
+    const char *wg = std::getenv("ORBGPU_WINDOW_GRID_MIN");  // tuning / tests: smallest n_from that takes the grid
+    if (wg) ctx->window_grid_min_from = std::max(1, std::atoi(wg));
     const char *ls = std::getenv("ORBGPU_LINK_SCAN");  // 1: large-capacity frame links by the plain scan, not the grid
     ctx->link_plain_scan = ls && ls[0] == '1';
     const char *o = std::getenv("ORBGPU_SLICES");  // tuning aid: slices per batch, 0 / unset = automatic
@@ -746,6 +750,19 @@ static int match_device_locked(orbgpu_ctx *ctx, const orbgpu_window_args &a, int
   if (a.n_from == 0) {
     HIP_TRY(hipMemsetAsync(d_from_idx, 0xff, sizeof(int32_t) * (size_t)a.n_to, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_dist, 0, sizeof(uint32_t) * (size_t)a.n_to, ctx->stream));
+    return ORBGPU_OK;
+  }
+  if (a.to_xy && a.n_to >= 64 && a.n_from >= ctx->window_grid_min_from && a.n_to < (1 << 20) && a.n_from < (1 << 20) &&
+      !ctx->window_plain_scan) {
+    // windowed search among many 'from' rows (below ~2000 a single search has too few wavefronts for the grid to pay): over the 64 x 48 search grid laid over the context's image (one segment, the same
+    // kernels as orbgpu_match_window_grid_segments_device; identical results, see there)
+    int rc = ensure_match_scratch(ctx, grid_match_scratch_bytes(1, a.n_to, a.n_from, a.n_from));
+    if (rc) return rc;
+    const orbgpu_segment one{0, a.n_to, 0, a.n_from};
+    launch_match_grid_segments(ctx, a, nullptr, 1, a.n_to, a.n_from, a.n_from, (double)ctx->params.width,
+                               (double)ctx->params.height, d_from_idx, reinterpret_cast<unsigned *>(d_dist),
+                               ctx->d_match_scratch, &one);
+    HIP_TRY(hipGetLastError());
     return ORBGPU_OK;
   }
   int rc = ensure_match_scratch(ctx, match_scratch_size(a.n_to, a.n_from));

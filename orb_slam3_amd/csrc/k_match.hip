@@ -362,8 +362,8 @@ __global__ __launch_bounds__(256) void k_snn_segments_resolve(const orbgpu_segme
                                                               int *__restrict__ from_idx,
                                                               const unsigned *__restrict__ dist,
                                                               const unsigned long long *__restrict__ claim,
-                                                              int max_to) {
-  const orbgpu_segment sg = segs[blockIdx.y];
+                                                              int max_to, orbgpu_segment seg0) {
+  const orbgpu_segment sg = segs ? segs[blockIdx.y] : seg0;
   const int li = blockIdx.x * 256 + threadIdx.x;
   if (li >= min(sg.to_count, max_to)) return;
   const int i = sg.to_begin + li;
@@ -432,6 +432,7 @@ struct GridBuildArgs {
   double2 *s_xy;
   int *s_lv;
   int *error_flag;  // ORBGPU_ERR_SEGMENT_SIZE when a range is larger than out_stride (the surplus is ignored)
+  int one[4];       // ranges == nullptr: the single range / segment, by value
 };
 
 // count rows, of which keep(i) take part; getxy(i) = position; emit(k, i): row i is the k-th of the binned order.
@@ -500,8 +501,8 @@ __device__ __forceinline__ int grid_build_core(int count, const GridDims &g, int
 template <bool CURVE, bool GATHER>
 __device__ __forceinline__ void grid_build_body(const GridBuildArgs &a, const GridDims &g, int r, int *hist, int *cursor,
                                                 int *wsum) {
-  const int begin = a.ranges[r * a.range_stride + a.range_off];
-  int count = a.ranges[r * a.range_stride + a.range_off + 1];
+  const int begin = a.ranges ? a.ranges[r * a.range_stride + a.range_off] : a.one[a.range_off];
+  int count = a.ranges ? a.ranges[r * a.range_stride + a.range_off + 1] : a.one[a.range_off + 1];
   if (count > a.out_stride) {  // the caller's max count was too small: stay inside this range's rows and say so
     if (threadIdx.x == 0 && a.error_flag) atomicExch(a.error_flag, ORBGPU_ERR_SEGMENT_SIZE);
     count = a.out_stride;
@@ -643,13 +644,13 @@ __device__ __forceinline__ void grid_scan(const ToWindow &tw, bool active, const
 }
 
 __global__ __launch_bounds__(256) void k_snn_grid(orbgpu_window_args a, const orbgpu_segment *__restrict__ segs,
-                                                  GridDims g, int to_stride, int from_stride,
+                                                  orbgpu_segment seg0, GridDims g, int to_stride, int from_stride,
                                                   const int *__restrict__ to_items, const int *__restrict__ cell_start,
                                                   const int *__restrict__ s_idx, const uint4 *__restrict__ s_desc,
                                                   const double2 *__restrict__ s_xy, const int *__restrict__ s_lv,
                                                   int *__restrict__ from_idx, unsigned *__restrict__ dist,
                                                   unsigned long long *__restrict__ claim) {
-  orbgpu_segment sg = segs[blockIdx.y];
+  orbgpu_segment sg = segs ? segs[blockIdx.y] : seg0;  // segs == nullptr: the one segment, by value
   sg.to_count = min(sg.to_count, to_stride);  // larger: flagged by the build kernel
   if ((int)(blockIdx.x * 256) >= sg.to_count) return;
   const int p = blockIdx.x * 256 + threadIdx.x;
@@ -1541,7 +1542,8 @@ void launch_match_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, con
   b.threshold = std::min(a.threshold, 256u);
   const dim3 grid((max_to_count + 255) / 256, n_segments);
   hipLaunchKernelGGL(k_snn_segments, grid, dim3(256), 0, c->stream, b, d_segs, d_from_idx, d_dist, claim);
-  hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim, INT_MAX);
+  hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim, INT_MAX,
+                     orbgpu_segment{});
 }
 
 size_t grid_build_scratch_bytes(int n_ranges, int max_count) { return (size_t)n_ranges * max_count * 4 + 256; }
@@ -1571,7 +1573,10 @@ size_t grid_match_scratch_bytes(int n_segments, int max_to_count, int max_from_c
 
 void launch_match_grid_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, const orbgpu_segment *d_segs,
                                 int n_segments, int max_to_count, int max_from_count, int n_from_total,
-                                double image_width, double image_height, int *d_from_idx, unsigned *d_dist, void *scratch) {
+                                double image_width, double image_height, int *d_from_idx, unsigned *d_dist, void *scratch,
+                                const orbgpu_segment *one) {
+  // d_segs == nullptr: the single segment *one (host memory), handed to the kernels by value
+  const orbgpu_segment seg0 = one ? *one : orbgpu_segment{};
   const size_t nt = (size_t)n_segments * max_to_count, nf = (size_t)n_segments * max_from_count;
   unsigned char *sp = reinterpret_cast<unsigned char *>(scratch);
   auto take = [&](size_t bytes) {
@@ -1608,6 +1613,7 @@ void launch_match_grid_segments(const orbgpu_ctx *c, const orbgpu_window_args &a
   gf.s_xy = s_xy;
   gf.s_lv = s_lv;
   gf.error_flag = gt.error_flag = c->d_error_flag;
+  for (int q = 0; q < 4; q++) gf.one[q] = gt.one[q] = (&seg0.to_begin)[q];
   gt.xy = reinterpret_cast<const double2 *>(a.to_xy);
   gt.ranges = ranges;
   gt.range_stride = 4;
@@ -1619,10 +1625,10 @@ void launch_match_grid_segments(const orbgpu_ctx *c, const orbgpu_window_args &a
   orbgpu_window_args b = a;
   b.threshold = std::min(a.threshold, 256u);
   const dim3 grid((max_to_count + 255) / 256, n_segments);
-  hipLaunchKernelGGL(k_snn_grid, grid, dim3(256), 0, c->stream, b, d_segs, g, max_to_count, max_from_count, to_items,
+  hipLaunchKernelGGL(k_snn_grid, grid, dim3(256), 0, c->stream, b, d_segs, seg0, g, max_to_count, max_from_count, to_items,
                      cell_start, s_idx, s_desc, s_xy, s_lv, d_from_idx, d_dist, claim);
   hipLaunchKernelGGL(k_snn_segments_resolve, grid, dim3(256), 0, c->stream, d_segs, d_from_idx, d_dist, claim,
-                     max_to_count);
+                     max_to_count, seg0);
 }
 
 size_t group_scratch_bytes(int n_from, int n_slots) { return (size_t)n_from * 8 + (size_t)n_slots * 8 + 256; }

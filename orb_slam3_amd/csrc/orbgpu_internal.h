@@ -148,6 +148,8 @@ struct orbgpu_ctx {
                                        // [7], [8] bracket the blur on its own stream, [9] = all slices joined
   int ev_head = 0, ev_pending = 0;
   bool ev_full[ORBGPU_EV_SETS]{};      // that set holds every stage boundary, not only the FAST kernel's and the total
+  int window_grid_min_from = 2048;  // orbgpu_match_window[_device]: n_from from which the search grid is used
+  bool window_plain_scan = false;  // ORBGPU_WINDOW_SCAN=1: orbgpu_match_window[_device] never uses the search grid
   bool link_plain_scan = false;   // ORBGPU_LINK_SCAN=1: large-capacity links by the plain predicated scan (comparison)
   bool bruteforce_mfma = false;  // exploratory engine of the brute-force matcher (orbgpu_set_bruteforce_engine)
   bool stage_timing = false;           // record every stage boundary (each event costs a few microseconds between kernels)
@@ -221,7 +223,8 @@ void launch_grid_build(const orbgpu_ctx *c, const double *d_xy, const int *d_ran
 size_t grid_match_scratch_bytes(int n_segments, int max_to_count, int max_from_count, int n_from_total);
 void launch_match_grid_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, const orbgpu_segment *d_segs,
                                 int n_segments, int max_to_count, int max_from_count, int n_from_total,
-                                double image_width, double image_height, int *d_from_idx, unsigned *d_dist, void *scratch);
+                                double image_width, double image_height, int *d_from_idx, unsigned *d_dist, void *scratch,
+                                const orbgpu_segment *one = nullptr);
 void launch_match_segments(const orbgpu_ctx *c, const orbgpu_window_args &a, const orbgpu_segment *d_segs, int n_segments,
                            int max_to_count, int n_from_total, int *d_from_idx, unsigned *d_dist, void *scratch);
 size_t group_scratch_bytes(int n_from, int n_slots);

@@ -498,3 +498,52 @@ def test_grid_segments_flags_an_understated_maximum(fe):
                                                         oi.data_ptr(), od.data_ptr()) == 0
     assert lib.orbgpu_synchronize(fe.handle) == 0
     assert (oi.cpu().numpy() == np.arange(n)).all()              # every row finds itself
+
+
+@pytest.mark.parametrize("n_to,n_from,grid_min", [(300, 280, "1"), (64, 256, "1"), (2500, 2600, None), (1000, 5000, None)])
+def test_single_window_search_over_the_grid(oracle, n_to, n_from, grid_min):
+    """orbgpu_match_window (host pointers, one search: the call SNNMatcher<ProjectionSearchIterator> makes) takes the search
+    grid from 2048 'from' rows on (ORBGPU_WINDOW_GRID_MIN lowers that for the small cases here): same results as the
+    oracle and as a context that never uses the grid (ORBGPU_WINDOW_SCAN=1)."""
+    import os
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    rng = np.random.default_rng(n_to + n_from)
+    W, H = 1280, 720
+    from_desc = rng.integers(0, 256, (n_from, 32), dtype=np.uint8)
+    to_desc = rng.integers(0, 256, (n_to, 32), dtype=np.uint8)
+    from_xy = rng.uniform((-10, -10), (W + 10, H + 10), (n_from, 2))
+    to_xy = rng.uniform((-10, -10), (W + 10, H + 10), (n_to, 2))
+    k = min(n_to, n_from) // 2
+    i, j = rng.choice(n_to, k, replace=False), rng.choice(n_from, k, replace=False)
+    to_desc[i] = from_desc[j]
+    to_desc[i, :2] ^= rng.integers(0, 256, (k, 2)).astype(np.uint8)
+    to_xy[i] = from_xy[j] + rng.uniform(-5, 5, (k, 2))
+    to_lv = rng.integers(0, 8, n_to).astype(np.int32)
+    from_lv = rng.integers(0, 8, n_from).astype(np.int32)
+    to_lv[i] = np.clip(from_lv[j] + rng.integers(-1, 2, k), 0, 7)
+    to_desc[i[1]], to_xy[i[1]], to_lv[i[1]] = to_desc[i[0]], to_xy[i[0]], to_lv[i[0]]      # contested claim
+    win = (np.float64(15.0) * np.float64(1.2) ** to_lv).astype(np.uint64)
+    lmin, lmax = np.maximum(to_lv - 1, 0).astype(np.int32), (to_lv + 1).astype(np.int32)
+    active = (rng.uniform(size=n_to) < 0.9).astype(np.uint8)
+    omf, omd = oracle.snn_match(to_desc, from_desc, 100, 0.9, to_xy=to_xy, to_window=win, to_min_level=lmin,
+                                to_max_level=lmax, to_active=active, from_xy=from_xy, from_level=from_lv)
+    assert (omf >= 0).sum() > k // 3
+    for env in ({"ORBGPU_WINDOW_GRID_MIN": grid_min} if grid_min else {}, {"ORBGPU_WINDOW_SCAN": "1"}):
+        os.environ.update(env)
+        try:
+            ctx = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_features=1000)
+        finally:
+            for name in env:
+                os.environ.pop(name, None)
+        a = _lib.WindowArgs(_lib.ptr(to_desc), _lib.ptr(to_xy), _lib.ptr(win), _lib.ptr(lmin), _lib.ptr(lmax),
+                            _lib.ptr(active), n_to, _lib.ptr(from_desc), _lib.ptr(from_xy), _lib.ptr(from_lv), n_from, 100, 0.9)
+        gi, gd = np.zeros(n_to, np.int32), np.zeros(n_to, np.uint32)
+        import ctypes as C
+        for rep in range(2):
+            assert lib.orbgpu_match_window(ctx.handle, C.byref(a), _lib.ptr(gi), _lib.ptr(gd)) == 0, \
+                lib.orbgpu_last_error(ctx.handle)
+        assert np.array_equal(gi, omf), env
+        assert np.array_equal(gd[omf >= 0], omd[omf >= 0]), env
+        ctx.close()
