@@ -416,6 +416,21 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       HIP_TRY(dmalloc(&ctx->d_fast_groups, groups.size()));
       HIP_TRY(hipMemcpy(ctx->d_fast_groups, groups.data(), groups.size() * sizeof(short), hipMemcpyHostToDevice));
     }
+    {
+      // blur tiles of one frame: (level, first column, first row, 0), so that the kernel finds its tile with one load
+      std::vector<short> bt;
+      for (int l = 0; l < g.levels; l++) {
+        const int tx = (g.lv[l].w + 127) / 128, ty = (g.lv[l].h + ORBGPU_BLUR_TILE_H - 1) / ORBGPU_BLUR_TILE_H;
+        for (int t = 0; t < tx * ty; t++) {
+          bt.push_back((short)l);
+          bt.push_back((short)((t % tx) * 128));
+          bt.push_back((short)((t / tx) * ORBGPU_BLUR_TILE_H));
+          bt.push_back(0);
+        }
+      }
+      HIP_TRY(dmalloc(&ctx->d_blur_tiles, bt.size()));
+      HIP_TRY(hipMemcpy(ctx->d_blur_tiles, bt.data(), bt.size() * sizeof(short), hipMemcpyHostToDevice));
+    }
     HIP_TRY(dmalloc(&ctx->d_cells, B * g.cells_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cands, B * g.cands_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cands_packed, B * g.cands_per_frame));
@@ -451,7 +466,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes,
-                   ctx->d_error_flag, ctx->d_fast_groups};
+                   ctx->d_error_flag, ctx->d_fast_groups, ctx->d_blur_tiles};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
   void *hptrs[] = {ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};

@@ -162,30 +162,34 @@ typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
 __device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
-// horizontal 7-tap of the pixel whose first tap is byte B (1..4) of the 12-byte window {w0,w1,w2}: two byte-aligned
-// dwords (taps 0..3 and 4..7) and two v_dot4_u32_u8 against the kernel (18 34 48 56 | 48 34 18 0); <= 65280
-template <int B>
+// horizontal 7-tap of pixel P (0..3) of the middle dword of the 12-byte window {w0,w1,w2}: the pixel's first tap is byte
+// 1 + P of the window, so the 7 taps are spread over two or three ALIGNED dwords; each takes one v_dot4_u32_u8 against
+// the kernel (18 34 48 56 48 34 18) shifted to where its bytes fall -- no byte realignment.  <= 65280
+template <int P>
 __device__ __forceinline__ unsigned hblur_px(const unsigned (&w)[3]) {
-  constexpr unsigned K0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), K1 = 48u | (34u << 8) | (18u << 16);
-  // v_alignbyte_b32 shifts by 0..3 bytes: B == 4 is the aligned case
-  const unsigned t0 = B == 4 ? w[1] : __builtin_amdgcn_alignbyte(w[1], w[0], B & 3);   // bytes B .. B+3
-  const unsigned t1 = B == 4 ? w[2] : __builtin_amdgcn_alignbyte(w[2], w[1], B & 3);   // bytes B+4 .. B+7
-  return __builtin_amdgcn_udot4(t1, K1, __builtin_amdgcn_udot4(t0, K0, 0u, false), false);
+  constexpr unsigned long long K = 18ull | (34ull << 8) | (48ull << 16) | (56ull << 24) | (48ull << 32) | (34ull << 40) |
+                                   (18ull << 48);
+  // byte j of the 12-byte window carries tap j - (1 + P): the kernel as a 96-bit constant shifted left by 1 + P bytes
+  constexpr int SH = 8 * (1 + P);
+  constexpr unsigned K0 = (unsigned)(K << SH), K1 = (unsigned)(SH == 32 ? K : (K >> (32 - SH))),
+                     K2 = (unsigned)(SH == 32 ? (K >> 32) : (K >> (64 - SH)));
+  unsigned acc = 0;
+  if (K0) acc = __builtin_amdgcn_udot4(w[0], K0, acc, false);
+  acc = __builtin_amdgcn_udot4(w[1], K1, acc, false);
+  if (K2) acc = __builtin_amdgcn_udot4(w[2], K2, acc, false);
+  return acc;
 }
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g,
-                                              int n_frames, Level0Src lvl0) {
+                                              int n_frames, Level0Src lvl0, const short4 *__restrict__ tiles) {
   __shared__ unsigned tile[BT_ROWS * TILE_DW];
   __shared__ __attribute__((aligned(16))) unsigned hbuf[BT_PAIRS * TILE_W];  // (h[2m][x], h[2m+1][x]) per dword
   // tile -> (level, tile x, tile y)
-  int t, frame, l = 0;
+  int t, frame;
   if (!xcd_item_frame(g.btiles_per_frame, n_frames, t, frame)) return;
-#pragma unroll 1
-  while (l + 1 < g.levels && t >= g.lv[l + 1].btile_off) l++;
+  const short4 bt = tiles[t];
+  const int l = bt.x, x0 = bt.y, y0 = bt.z;
   const LevelGeom L = g.lv[l];
-  t -= L.btile_off;
-  const int tiles_x = (L.w + TILE_W - 1) / TILE_W;
-  const int x0 = (t % tiles_x) * TILE_W, y0 = (t / tiles_x) * BT_H;
   const size_t base = (size_t)frame * g.frame_bytes + L.off;
   const uint8_t *src = level_src(pyr, g, lvl0, frame, l, L.off);
 
@@ -203,10 +207,10 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     }
     // window bytes 0..11 = columns 4c-4 .. 4c+7 (relative to x0); pixel p has its centre at byte 4+p, first tap 1+p
     uint4 o;  // per pixel (row 2rp, row 2rp+1) as u16 halves
-    o.x = hblur_px<1>(w0) | (hblur_px<1>(w1) << 16);
-    o.y = hblur_px<2>(w0) | (hblur_px<2>(w1) << 16);
-    o.z = hblur_px<3>(w0) | (hblur_px<3>(w1) << 16);
-    o.w = hblur_px<4>(w0) | (hblur_px<4>(w1) << 16);
+    o.x = hblur_px<0>(w0) | (hblur_px<0>(w1) << 16);
+    o.y = hblur_px<1>(w0) | (hblur_px<1>(w1) << 16);
+    o.z = hblur_px<2>(w0) | (hblur_px<2>(w1) << 16);
+    o.w = hblur_px<3>(w0) | (hblur_px<3>(w1) << 16);
     *reinterpret_cast<uint4 *>(&hbuf[rp * TILE_W + 4 * c]) = o;
   }
   __syncthreads();
@@ -272,5 +276,6 @@ void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level) {
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs) {
   dim3 grid(c->geom.btiles_per_frame * xcd_frames(fs.n));
   const size_t off = (size_t)fs.f0 * c->geom.frame_bytes;
-  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, fs.stream, c->d_pyr + off, c->d_blur + off, c->geom, fs.n, slice_lvl0(c, fs));
+  hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, fs.stream, c->d_pyr + off, c->d_blur + off, c->geom, fs.n, slice_lvl0(c, fs),
+                     reinterpret_cast<const short4 *>(c->d_blur_tiles));
 }

@@ -115,6 +115,7 @@ struct orbgpu_ctx {
   bool no_zero_copy = false;      // ORBGPU_NO_ZERO_COPY=1: always copy level 0 into the slab (cross-check path)
   short *d_fast_groups = nullptr; // FastGroup table of k_fast_cells (level, cell row, first cell, cells), one frame's worth
   int n_fast_groups = 0;
+  short *d_blur_tiles = nullptr;  // (level, x0, y0, 0) per blur tile of one frame
   int fast_lds_rows = 0;          // tallest cell of any level: sizes the dynamic LDS of k_fast_cells
   int n_slices = 1;               // slices a batch is cut into (ORBGPU_SLICES overrides)
   XTab *d_xtab = nullptr;
