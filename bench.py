@@ -264,7 +264,7 @@ def main():
     barrier()
     stt = fe.stage_times()
     fe.set_stage_timing(False)
-    st = np.array([stt[k] for k in ("pyramid", "fast_score", "cells", "quadtree", "blur", "orient_describe", "total")])
+    st = np.array([stt[k] for k in ("pyramid", "fast_score", "orient", "quadtree", "blur", "describe", "total")])
     st[1], st[6] = fast_ms_timed, extract_ms_timed    # what the roofline and pipeline objects use: the timed region's
     # the link matcher alone, outside the timed region (informational)
     link_ms = 0.0
@@ -354,16 +354,17 @@ def main():
                 "extract_only_frames_per_s": round(B / ext_s, 1) if ext_s > 0 else 0.0,
                 "achieved_GBps": round(A * B / ext_s / 1e9, 2) if ext_s > 0 else 0.0,
                 "frac_of_8TBps": round(A * B / ext_s / 1e9 / hbm_peak, 5) if ext_s > 0 else 0.0,
-                "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast_score", "cells", "quadtree", "blur", "orient_describe"), st[:6])},
+                "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast_score", "orient", "quadtree", "blur", "describe"), st[:6])},
                 "link_match_ms_per_batch": round(link_ms, 3),
                 "stage_ms_source": "fast_score and extract_ms_per_batch: HIP events inside the timed steps; the other stages: "
                                    "a separate pass right after them with every stage boundary recorded "
                                    "(orbgpu_set_stage_timing; the extra events cost ~2.5 % of a step)"}
-    # SURVEY 8d's decomposition of A per stage, each against its own stage time (cells / quadtree have no
-    # algorithmic bytes of their own: their traffic is implementation intermediates)
+    # SURVEY 8d's decomposition of A per stage, each against its own stage time (the quadtree has no algorithmic bytes of
+    # its own: its traffic is implementation intermediates; the orientation kernel runs beside the blur, off the
+    # critical path)
     px0, px7 = g.w[0] * g.h[0], g.w[g.levels - 1] * g.h[g.levels - 1]
     stage_bytes = {"pyramid": 2 * P - px0 - px7, "fast_score": P, "blur": 2 * P,
-                   "orient_describe": (2 * 961 + 56) * NF}
+                   "orient": 961 * NF, "describe": (961 + 56) * NF}
     pipeline["stage_algorithmic_GBps"] = {
         k: round(stage_bytes[k] * B / (pipeline["stage_ms"][k] * 1e-3) / 1e9, 1) if pipeline["stage_ms"][k] > 0 else 0.0
         for k in stage_bytes}
@@ -373,7 +374,7 @@ def main():
     # counts per launch come from the committed counter pass (they do not change from run to run), times from this run
     if sq:
         stage_of = {"k_resize_level": ("pyramid", g.levels - 1), "k_fast_cells": ("fast_score", 1), "k_quadtree": ("quadtree", 1),
-                    "k_blur": ("blur", 1), "k_orient_describe": ("orient_describe", 1)}
+                    "k_blur": ("blur", 1), "k_orient": ("orient", 1), "k_describe": ("describe", 1)}
         vi = {}
         for kname, (stage, launches) in stage_of.items():
             ms = pipeline["stage_ms"].get(stage, 0.0)

@@ -434,8 +434,8 @@ int orbgpu_bowdb_query(orbgpu_bowdb *db, const uint32_t *q_words, const double *
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-stage GPU time in milliseconds (HIP events on the context's stream), averaged over the extract calls
  * enqueued since the last orbgpu_synchronize / orbgpu_stage_times (at most the last 32); waits for the stream.
- * [0] pyramid [1] FAST score + cell NMS / fallback / compaction (one fused kernel) [2] 0 (that stage has no kernel of its
- * own any more) [3] quadtree [4] blur [5] orientation + descriptor [6] total.  With more than one slice per batch
+ * [0] pyramid [1] FAST score + cell NMS / fallback / compaction (one fused kernel) [2] orientation (its kernel runs behind
+ * the quadtree and beside the blur, off the critical path) [3] quadtree [4] blur [5] descriptor [6] total.  With more than one slice per batch
  * (orbgpu_set_batch_slices) [0]..[5] are the kernels of slice 0 -- its share of the frames, running beside the other
  * slices -- and [6] still spans the whole batch.  Used by bench.py for the roofline line. */
 int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms7);

@@ -240,6 +240,8 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     if (launch_quadtree(ctx, fs, budget) != 0)
       return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
     if (timed) HIP_TRY(hipEventRecord(ev[4], fs.stream));
+    launch_orient(ctx, fs);  // IC_Angle needs the unblurred levels only: beside the blur, behind the quadtree
+    if (timed) HIP_TRY(hipEventRecord(ev[3], fs.stream));
     HIP_TRY(hipStreamWaitEvent(fb.stream, sev[0], 0));
     if (timed) HIP_TRY(hipEventRecord(ev[7], fb.stream));
     launch_blur(ctx, fb);
@@ -247,7 +249,7 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     HIP_TRY(hipEventRecord(sev[1], fb.stream));
     HIP_TRY(hipStreamWaitEvent(fs.stream, sev[1], 0));
     if (timed) HIP_TRY(hipEventRecord(ev[5], fs.stream));
-    launch_orient_describe(ctx, fs, d_kp, d_desc, capacity, d_n_out);
+    launch_describe(ctx, fs, d_kp, d_desc, capacity, d_n_out);
     if (timed) HIP_TRY(hipEventRecord(ev[6], fs.stream));
     if (s > 0) {  // join
       HIP_TRY(hipEventRecord(sev[2], fs.stream));
@@ -279,6 +281,7 @@ int finish_pipeline(orbgpu_ctx *ctx) {
       acc[0] += elapsed(ev[0], ev[1]);
       acc[1] += elapsed(ev[1], ev[2]);  // FAST score + cells; [2] (cells) has no kernel of its own any more
       if (ctx->ev_full[(ctx->ev_head - k + ORBGPU_EV_SETS) % ORBGPU_EV_SETS]) {
+        acc[2] += elapsed(ev[4], ev[3]);  // orientation, behind the quadtree and beside the blur
         acc[3] += elapsed(ev[2], ev[4]);
         acc[4] += elapsed(ev[7], ev[8]);  // blur, on its own stream (overlaps the quadtree stage)
         acc[5] += elapsed(ev[5], ev[6]);
@@ -443,6 +446,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     *ctx->h_error_flag = 0;
     HIP_TRY(dmalloc(&ctx->d_kp_xy, B * g.kps_per_frame));
     HIP_TRY(dmalloc(&ctx->d_kp_count, B * g.levels));
+    HIP_TRY(dmalloc(&ctx->d_kp_angle, B * g.kps_per_frame));
     ctx->out_capacity = g.kps_per_frame;
     HIP_TRY(dmalloc(&ctx->d_out_kp, B * ctx->out_capacity));
     HIP_TRY(dmalloc(&ctx->d_out_desc, B * ctx->out_capacity * 32));
@@ -464,7 +468,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
-                   ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count,
+                   ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count, ctx->d_kp_angle,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes,
                    ctx->d_error_flag, ctx->d_fast_groups, ctx->d_blur_tiles};
   for (void *p : dptrs)

@@ -96,49 +96,29 @@ constexpr int PATCH_DW = PW * PDW + 11;
 // flight, not for instruction count: a wave owns four keypoints, the blurred patches go straight from global memory
 // to LDS (global_load_lds: no staging registers, 8 waves per SIMD), and everything that depends only on the slot is
 // forced wave-uniform (readfirstlane) so it runs on the scalar ALU.
-__global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__restrict__ pyr,
-                                                              const uint8_t *__restrict__ blur, DeviceGeom g,
-                                                              const short2 *__restrict__ kp_xy,
-                                                              const int *__restrict__ kp_count,
-                                                              orbgpu_keypoint *__restrict__ out_kp,
-                                                              uint8_t *__restrict__ out_desc, int capacity,
-                                                              int *__restrict__ out_n, int n_frames, Level0Src lvl0,
-                                                              int *__restrict__ error_flag) {
-  __shared__ unsigned patch[KPG][PATCH_DW];
-  __shared__ float s_angle[KPG];
-  __shared__ float s_cs[KPG][2];
-  __shared__ int s_prefix[ORBGPU_MAX_LEVELS];
+// k_orient: IC_Angle of every keypoint on the unblurred level, one wave per 4 keypoints.  Runs right after the quadtree,
+// beside the blur (it is bound by its scattered loads, the blur by the vector ALU), and leaves the angle in
+// d_angle[frame][slot] for k_describe.
+__global__ __launch_bounds__(64 * KPB) void k_orient(const uint8_t *__restrict__ pyr, DeviceGeom g,
+                                                     const short2 *__restrict__ kp_xy, const int *__restrict__ kp_count,
+                                                     float *__restrict__ kp_angle, int n_frames, Level0Src lvl0) {
   int f, group;
   if (!xcd_item_frame((g.kps_per_frame + KPG - 1) / KPG, n_frames, group, f)) return;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int *cnt = kp_count + f * g.levels;
-  // inclusive prefix of the per-level counts, once per workgroup (16 lanes of wave 0); read after the barriers
-  if (threadIdx.x < ORBGPU_MAX_LEVELS) {
-    int v = (int)threadIdx.x < g.levels ? cnt[threadIdx.x] : 0;
-#pragma unroll
-    for (int o = 1; o < ORBGPU_MAX_LEVELS; o <<= 1) {
-      const int u = __shfl_up(v, o);
-      if ((int)threadIdx.x >= o) v += u;
-    }
-    s_prefix[threadIdx.x] = v;
-  }
-
-  int slot[KPW], lv[KPW], idx[KPW], cx[KPW], cy[KPW], sh[KPW];
-  bool valid[KPW];  // wave-uniform; invalid halves only take part in the barriers
+  int slot[KPW], lv[KPW], cx[KPW], cy[KPW];
+  bool valid[KPW];
   unsigned l_off[KPW];
   int l_pitch[KPW];
-  float angle[KPW];
 #pragma unroll
   for (int h = 0; h < KPW; h++) {
     slot[h] = group * KPG + wave * KPW + h;
     lv[h] = level_of(g.kp_offs, slot[h]);
     const LevelGeom &L = g.lv[lv[h]];
-    idx[h] = slot[h] - L.kp_off;
     l_off[h] = L.off;
     l_pitch[h] = L.pitch;
-    valid[h] = slot[h] < g.kps_per_frame && idx[h] < cnt[lv[h]];
-    cx[h] = cy[h] = sh[h] = 0;
-    angle[h] = 0.f;
+    valid[h] = slot[h] < g.kps_per_frame && slot[h] - L.kp_off < cnt[lv[h]];
+    cx[h] = cy[h] = 0;
   }
   short2 xy[KPW];
 #pragma unroll
@@ -146,30 +126,13 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
     xy[h] = make_short2(0, 0);
     if (valid[h]) xy[h] = kp_xy[(size_t)f * g.kps_per_frame + slot[h]];
   }
-  // ---- blurred patches: 39 rows x 11 aligned dwords, 5 rows = 55 lanes per step, global -> LDS directly.  The LDS
-  //      address of (row 5k + lane/11, dword lane%11) is 55k + lane, which is what the instruction writes (base + 4*lane)
-  const int psub = lane / PDW, pc4 = 4 * (lane - psub * PDW);
-#pragma unroll
-  for (int h = 0; h < KPW; h++) {
-    if (!valid[h]) continue;
-    cx[h] = __builtin_amdgcn_readfirstlane((int)xy[h].x);
-    cy[h] = __builtin_amdgcn_readfirstlane((int)xy[h].y);
-    const int xb = (cx[h] - PR) & ~3;
-    sh[h] = (cx[h] - PR) - xb;
-    const uint8_t *bsrc = blur + (size_t)f * g.frame_bytes + l_off[h] + (size_t)(cy[h] - PR) * l_pitch[h] + xb;
-    const unsigned poff = (unsigned)(psub * l_pitch[h] + pc4);
-    unsigned *P = patch[wave * KPW + h];
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (lane < 5 * PDW && 5 * k + psub < PW)
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned *>(bsrc + (poff + (unsigned)(5 * k * l_pitch[h]))),
-                                         P + 55 * k, 4, 0, 0);
-  }
-  // ---- orientation on the unblurred level (IC_Angle): 31 rows x 9 aligned dwords, 7 rows = 63 lanes per step
+  // 31 rows x 9 aligned dwords, 7 rows = 63 lanes per step
   const int osub = lane / ODW, oc4 = 4 * (lane - osub * ODW);
   unsigned ov[KPW][5];
 #pragma unroll
   for (int h = 0; h < KPW; h++) {
+    cx[h] = __builtin_amdgcn_readfirstlane((int)xy[h].x);
+    cy[h] = __builtin_amdgcn_readfirstlane((int)xy[h].y);
     const int xo = (cx[h] - ORB_HALF_PATCH) & ~3;
     const uint8_t *osrc = level_src(pyr, g, lvl0, f, lv[h], l_off[h]) + (size_t)(cy[h] - ORB_HALF_PATCH) * l_pitch[h] + xo;
     const unsigned ooff = (unsigned)(osub * l_pitch[h] + oc4);
@@ -201,16 +164,88 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
       m10 += __shfl_xor(m10, off);
       m01 += __shfl_xor(m01, off);
     }
-    angle[h] = fast_atan2_deg((float)m01, (float)m10);
-    if (lane == 0) s_angle[wave * KPW + h] = angle[h];
+    const float ang = fast_atan2_deg((float)m01, (float)m10);
+    if (lane == 0) kp_angle[(size_t)f * g.kps_per_frame + slot[h]] = ang;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the direct-to-LDS patch loads have landed
-  __syncthreads();
-  // ---- cos/sin for the whole workgroup by 16 lanes of wave 0: float(angle_deg) * (double)(pi/180) -> float,
-  //      cos/sin evaluated in double and rounded to float
+}
+
+// k_describe: rotated BRIEF on the blurred level + the output records.  Its cost is the patch gather, so it is organised
+// for loads in flight: a wave owns four keypoints, the blurred patches go straight from global memory to LDS
+// (global_load_lds: no staging registers), and everything that depends only on the slot is forced wave-uniform
+// (readfirstlane) so it runs on the scalar ALU.
+__global__ __launch_bounds__(64 * KPB) void k_describe(const uint8_t *__restrict__ blur, DeviceGeom g,
+                                                       const short2 *__restrict__ kp_xy,
+                                                       const int *__restrict__ kp_count,
+                                                       const float *__restrict__ kp_angle,
+                                                       orbgpu_keypoint *__restrict__ out_kp,
+                                                       uint8_t *__restrict__ out_desc, int capacity,
+                                                       int *__restrict__ out_n, int n_frames,
+                                                       int *__restrict__ error_flag) {
+  __shared__ unsigned patch[KPG][PATCH_DW];
+  __shared__ float s_cs[KPG][2];
+  __shared__ int s_prefix[ORBGPU_MAX_LEVELS];
+  int f, group;
+  if (!xcd_item_frame((g.kps_per_frame + KPG - 1) / KPG, n_frames, group, f)) return;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int *cnt = kp_count + f * g.levels;
+  // inclusive prefix of the per-level counts, once per workgroup (16 lanes of wave 0); read after the barriers
+  if (threadIdx.x < ORBGPU_MAX_LEVELS) {
+    int v = (int)threadIdx.x < g.levels ? cnt[threadIdx.x] : 0;
+#pragma unroll
+    for (int o = 1; o < ORBGPU_MAX_LEVELS; o <<= 1) {
+      const int u = __shfl_up(v, o);
+      if ((int)threadIdx.x >= o) v += u;
+    }
+    s_prefix[threadIdx.x] = v;
+  }
+
+  int slot[KPW], lv[KPW], idx[KPW], cx[KPW], cy[KPW], sh[KPW];
+  bool valid[KPW];  // wave-uniform; invalid ones only take part in the barriers
+  unsigned l_off[KPW];
+  int l_pitch[KPW];
+#pragma unroll
+  for (int h = 0; h < KPW; h++) {
+    slot[h] = group * KPG + wave * KPW + h;
+    lv[h] = level_of(g.kp_offs, slot[h]);
+    const LevelGeom &L = g.lv[lv[h]];
+    idx[h] = slot[h] - L.kp_off;
+    l_off[h] = L.off;
+    l_pitch[h] = L.pitch;
+    valid[h] = slot[h] < g.kps_per_frame && idx[h] < cnt[lv[h]];
+    cx[h] = cy[h] = sh[h] = 0;
+  }
+  short2 xy[KPW];
+#pragma unroll
+  for (int h = 0; h < KPW; h++) {
+    xy[h] = make_short2(0, 0);
+    if (valid[h]) xy[h] = kp_xy[(size_t)f * g.kps_per_frame + slot[h]];
+  }
+  // ---- blurred patches: 39 rows x 11 aligned dwords, 5 rows = 55 lanes per step, global -> LDS directly.  The LDS
+  //      address of (row 5k + lane/11, dword lane%11) is 55k + lane, which is what the instruction writes (base + 4*lane)
+  const int psub = lane / PDW, pc4 = 4 * (lane - psub * PDW);
+#pragma unroll
+  for (int h = 0; h < KPW; h++) {
+    if (!valid[h]) continue;
+    cx[h] = __builtin_amdgcn_readfirstlane((int)xy[h].x);
+    cy[h] = __builtin_amdgcn_readfirstlane((int)xy[h].y);
+    const int xb = (cx[h] - PR) & ~3;
+    sh[h] = (cx[h] - PR) - xb;
+    const uint8_t *bsrc = blur + (size_t)f * g.frame_bytes + l_off[h] + (size_t)(cy[h] - PR) * l_pitch[h] + xb;
+    const unsigned poff = (unsigned)(psub * l_pitch[h] + pc4);
+    unsigned *P = patch[wave * KPW + h];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (lane < 5 * PDW && 5 * k + psub < PW)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned *>(bsrc + (poff + (unsigned)(5 * k * l_pitch[h]))),
+                                         P + 55 * k, 4, 0, 0);
+  }
+  // ---- cos/sin of the workgroup's 16 keypoints by 16 lanes of wave 0 while the patches are in flight:
+  //      float(angle_deg) * (double)(pi/180) -> float, cos/sin evaluated in double and rounded to float
   if (threadIdx.x < KPG) {
+    const int sl = group * KPG + (int)threadIdx.x;
+    const float adeg = sl < g.kps_per_frame ? kp_angle[(size_t)f * g.kps_per_frame + sl] : 0.f;
     const double factorPI = 3.14159265358979323846 / 180.;
-    const float ang = (float)((double)s_angle[threadIdx.x] * factorPI);
+    const float ang = (float)((double)adeg * factorPI);
 #ifdef ORBGPU_TRIG_F32
     // build-time variant (make TRIG=f32): the float overloads, as a reference build that has <math.h> in scope would
     // call.  The device's cosf / sinf are not glibc's bit for bit: this switch measures sensitivity, it claims no parity
@@ -223,6 +258,7 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
     s_cs[threadIdx.x][1] = (float)sn;
 #endif
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the direct-to-LDS patch loads have landed
   __syncthreads();
   const int total = s_prefix[ORBGPU_MAX_LEVELS - 1];
   if (group == 0 && threadIdx.x == 0) {
@@ -235,7 +271,7 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
 #pragma unroll
   for (int h = 0; h < KPW; h++) any_valid |= valid[h];
   if (total > capacity || !any_valid) return;
-  // the lane's 4 test patterns (pattern_, 16 bytes each), shared by the wave's two keypoints
+  // the lane's 4 test patterns (pattern_, 16 bytes each), shared by the wave's keypoints
   const float4 *pat = reinterpret_cast<const float4 *>(c_pattern.v);
   float4 ptn[4];
 #pragma unroll
@@ -271,7 +307,7 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
         k.x *= (double)L.scale_f;
         k.y *= (double)L.scale_f;
       }
-      k.angle = angle[h];
+      k.angle = kp_angle[(size_t)f * g.kps_per_frame + slot[h]];
       k.size = L.kp_size;
       k.level = l;
       k.reserved = 0;
@@ -282,15 +318,22 @@ __global__ __launch_bounds__(64 * KPB) void k_orient_describe(const uint8_t *__r
 
 }  // namespace
 
-void launch_orient_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
-                            int *d_n_out) {
+void launch_orient(const orbgpu_ctx *c, FrameSlice fs) {
   const DeviceGeom &g = c->geom;
   dim3 grid((g.kps_per_frame + KPG - 1) / KPG * xcd_frames(fs.n));
-  const size_t off = (size_t)fs.f0 * g.frame_bytes;
-  hipLaunchKernelGGL(k_orient_describe, grid, dim3(64 * KPB), 0, fs.stream, c->d_pyr + off, c->d_blur + off, g,
+  hipLaunchKernelGGL(k_orient, grid, dim3(64 * KPB), 0, fs.stream, c->d_pyr + (size_t)fs.f0 * g.frame_bytes, g,
                      c->d_kp_xy + (size_t)fs.f0 * g.kps_per_frame, c->d_kp_count + (size_t)fs.f0 * g.levels,
-                     d_kp + (size_t)fs.f0 * capacity, d_desc + (size_t)fs.f0 * capacity * 32, capacity, d_n_out + fs.f0, fs.n,
-                     slice_lvl0(c, fs), c->d_error_flag);
+                     c->d_kp_angle + (size_t)fs.f0 * g.kps_per_frame, fs.n, slice_lvl0(c, fs));
+}
+
+void launch_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
+                     int *d_n_out) {
+  const DeviceGeom &g = c->geom;
+  dim3 grid((g.kps_per_frame + KPG - 1) / KPG * xcd_frames(fs.n));
+  hipLaunchKernelGGL(k_describe, grid, dim3(64 * KPB), 0, fs.stream, c->d_blur + (size_t)fs.f0 * g.frame_bytes, g,
+                     c->d_kp_xy + (size_t)fs.f0 * g.kps_per_frame, c->d_kp_count + (size_t)fs.f0 * g.levels,
+                     c->d_kp_angle + (size_t)fs.f0 * g.kps_per_frame, d_kp + (size_t)fs.f0 * capacity,
+                     d_desc + (size_t)fs.f0 * capacity * 32, capacity, d_n_out + fs.f0, fs.n, c->d_error_flag);
 }
 
 // ------------------------------------------------------------------------------------------------

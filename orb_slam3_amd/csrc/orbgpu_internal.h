@@ -130,6 +130,7 @@ struct orbgpu_ctx {
   int *h_error_flag = nullptr;
   short2 *d_kp_xy = nullptr;      // [frame][kps_per_frame] level coordinates after the quadtree
   int *d_kp_count = nullptr;      // [frame][levels]
+  float *d_kp_angle = nullptr;    // [frame][kps_per_frame] IC_Angle in degrees (k_orient -> k_describe)
   // internal outputs used by the host-pointer entry points
   orbgpu_keypoint *d_out_kp = nullptr;
   uint8_t *d_out_desc = nullptr;
@@ -187,8 +188,9 @@ void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level);
 int build_fast_groups(const DeviceGeom &g, std::vector<short> &table);
 void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump);
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs);
-void launch_orient_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
-                            int *d_n_out);
+void launch_orient(const orbgpu_ctx *c, FrameSlice fs);
+void launch_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
+                     int *d_n_out);
 void launch_keypoint_geometry(const orbgpu_ctx *c, const orbgpu_camera &cam, const orbgpu_keypoint *d_kp, const int *d_n,
                               int n_frames, int capacity, double *d_undist, double *d_unproj, uint8_t *d_ok);
 void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t frame_stride, int stride, int n_frames);

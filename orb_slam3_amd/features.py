@@ -184,7 +184,7 @@ class ORBFeatureExtractor:
     def stage_times(self):
         ms = np.zeros(7, np.float32)
         self._check(self._lib.orbgpu_stage_times(self._h, _lib.ptr(ms)))
-        return dict(zip(("pyramid", "fast_score", "cells", "quadtree", "blur", "orient_describe", "total"), ms.tolist()))
+        return dict(zip(("pyramid", "fast_score", "orient", "quadtree", "blur", "describe", "total"), ms.tolist()))
 
     def popcount_peak(self):
         v = C.c_double(0)
