@@ -80,16 +80,19 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   return a;
 }
 
-constexpr int PR = 19;              // patch radius staged for the descriptor (taps reach <= 18.4 px)
-constexpr int PW = 2 * PR + 1;      // 39 rows
-constexpr int PDW = 11;             // aligned dwords per staged row: 39 bytes + up to 3 bytes of misalignment
-constexpr int PPITCH = PDW * 4;     // 44
+constexpr int PR = 18;              // patch radius staged for the descriptor: the pattern's points lie within 18.385 px
+                                    // of the centre (13, 13), so a rotated tap rounds to at most 18
+constexpr int PW = 2 * PR + 1;      // 37 rows
+constexpr int PDW = 10;             // aligned dwords per staged row: 37 bytes + up to 3 bytes of misalignment
+constexpr int PPITCH = PDW * 4;     // 40
+constexpr int PRI = 64 / PDW;       // rows per load instruction (6: 60 lanes)
+constexpr int PNI = (PW + PRI - 1) / PRI;  // load instructions per patch (7)
 constexpr int KPB = 4;              // waves per workgroup
 constexpr int KPW = 4;              // keypoints per wave, processed side by side: four times the loads in flight, and the
                                     // pattern loads / address math shared (measured per 256-frame batch: 8 waves x 2:
                                     // 0.256 ms, 4 x 4: 0.245, 2 x 4: 0.251, 6 x 4: 0.316, 8 x 4: 0.290)
 constexpr int KPG = KPB * KPW;      // keypoint slots per workgroup
-constexpr int PATCH_DW = PW * PDW + 11;
+constexpr int PATCH_DW = PW * PDW + PDW;
 
 // blockDim = 64 * KPB; 1-D grid over (slot group, frame) in XCD order.  The kernel is latency-bound (keypoint -> patch
 // -> orientation -> sin/cos -> taps is a chain of dependent memory round trips), so it is organised for loads in
@@ -220,8 +223,9 @@ __global__ __launch_bounds__(64 * KPB) void k_describe(const uint8_t *__restrict
     xy[h] = make_short2(0, 0);
     if (valid[h]) xy[h] = kp_xy[(size_t)f * g.kps_per_frame + slot[h]];
   }
-  // ---- blurred patches: 39 rows x 11 aligned dwords, 5 rows = 55 lanes per step, global -> LDS directly.  The LDS
-  //      address of (row 5k + lane/11, dword lane%11) is 55k + lane, which is what the instruction writes (base + 4*lane)
+  // ---- blurred patches: PW rows x PDW aligned dwords, PRI rows per step, global -> LDS directly.  The LDS address of
+  //      (row PRI k + lane / PDW, dword lane % PDW) is PRI PDW k + lane, which is what the instruction writes
+  //      (base + 4 * lane)
   const int psub = lane / PDW, pc4 = 4 * (lane - psub * PDW);
 #pragma unroll
   for (int h = 0; h < KPW; h++) {
@@ -234,10 +238,10 @@ __global__ __launch_bounds__(64 * KPB) void k_describe(const uint8_t *__restrict
     const unsigned poff = (unsigned)(psub * l_pitch[h] + pc4);
     unsigned *P = patch[wave * KPW + h];
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (lane < 5 * PDW && 5 * k + psub < PW)
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned *>(bsrc + (poff + (unsigned)(5 * k * l_pitch[h]))),
-                                         P + 55 * k, 4, 0, 0);
+    for (int k = 0; k < PNI; k++)
+      if (lane < PRI * PDW && PRI * k + psub < PW)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned *>(bsrc + (poff + (unsigned)(PRI * k * l_pitch[h]))),
+                                         P + PRI * PDW * k, 4, 0, 0);
   }
   // ---- cos/sin of the workgroup's 16 keypoints by 16 lanes of wave 0 while the patches are in flight:
   //      float(angle_deg) * (double)(pi/180) -> float, cos/sin evaluated in double and rounded to float
