@@ -346,7 +346,7 @@ def main():
                 "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P * B, "traffic_source": traffic_src,
                 "limiter": "instruction issue, not HBM: the kernel (FAST score + per-cell NMS, fallback and compaction, fused) "
                            "issues about one vector instruction per clock per CU, the measured ceiling of its mix "
-                           "(profiles/r2_hbm_traffic.json sq_counters_per_launch, profiles/r1_valu_rate.txt)"}
+                           "(profiles/r2_hbm_traffic.json sq_counters_per_launch, profiles/r2_valu_rate.txt)"}
     # whole extraction against SURVEY 8d's per-frame figure A = 5P - px0 - px7 + 1978 N
     A = 5 * P - g.w[0] * g.h[0] - g.w[g.levels - 1] * g.h[g.levels - 1] + 1978 * NF
     ext_s = st[6] * 1e-3
