@@ -317,7 +317,8 @@ def main():
                     "descriptor_pairs": desc_pairs, "ms": round(float(tt.item()) * 1e3, 3),
                     "descriptor_pairs_per_s": round(desc_pairs / float(tt.item()), 1),
                     "allgather_bytes_per_rank": int(k_local * cap * 64 + k_local * 4),
-                    "exchange": "torch.distributed all_gather_into_tensor (RCCL)" if world > 1 else "none (1 rank)",
+                    "exchange": (f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})"
+                                 if world > 1 else "none (1 rank)"),
                     "matches_rank0": int(nm.sum().item()), "includes": "all-gather + match + rotation filter, max over ranks"}
 
     if rank != 0:
