@@ -976,62 +976,75 @@ __global__ __launch_bounds__(256) void k_link_grid(const orbgpu_keypoint *__rest
 // level-0 'to' ids with level-0 'from' ids (area_to_iterator.h:24-43, area_to_pointee.h:44-48), so the two index
 // lists are compacted first (ascending, which keeps the reference's scan order) and only |to0| x |from0| pairs are
 // evaluated -- about 1/20 of N_to x N_from at 8 levels.  Lists, claims and per-'to' results live in LDS.
-template <class Pred>
+template <int NT, class Pred>
 __device__ __forceinline__ int block_compact_list(int n, int *list, int *s_wtot, Pred pred) {
-  // ascending list of i in [0, n) with pred(i); every thread of the 256-thread block calls it; returns the count
+  // ascending list of i in [0, n) with pred(i); every thread of the NT-thread block calls it; returns the count
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int base = 0;
-  for (int i0 = 0; i0 < n; i0 += 256) {
+  for (int i0 = 0; i0 < n; i0 += NT) {
     const int i = i0 + threadIdx.x;
     const bool f = i < n && pred(i);
     const unsigned long long bal = __ballot(f);
     if (lane == 0) s_wtot[wave] = __popcll(bal);
     __syncthreads();
-    int off = base;
-    for (int w = 0; w < wave; w++) off += s_wtot[w];
+    int off = base, all = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) {
+      off += w < wave ? s_wtot[w] : 0;
+      all += s_wtot[w];
+    }
     if (f) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-    base += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+    base += all;
     __syncthreads();
   }
   return base;
 }
 
-__global__ __launch_bounds__(256) void k_link_fused(const orbgpu_keypoint *__restrict__ kp, const uint8_t *__restrict__ desc,
-                                                    const int *__restrict__ n_kp, int capacity,
-                                                    const int *__restrict__ to_frame, const int *__restrict__ from_frame,
-                                                    double window, unsigned threshold, double ratio,
-                                                    int check_orientation, int *__restrict__ match,
-                                                    unsigned *__restrict__ dist, int *__restrict__ n_matches) {
+// LK_NT threads: the pair's work is a chain of short phases (two compactions, the scan, the claims, the rotation
+// histogram), each a few passes over ~1000 entries, so one workgroup per pair is bound by latency, not by work: 1024
+// threads shorten every pass fourfold, and the four 256-thread groups split each staged chunk of 'from' candidates
+// between them (46 -> see DESIGN.md for the measured time per 255 pairs).
+constexpr int LK_NT = 1024, LK_G = LK_NT / 256;
+__global__ __launch_bounds__(LK_NT) void k_link_fused(const orbgpu_keypoint *__restrict__ kp, const uint8_t *__restrict__ desc,
+                                                      const int *__restrict__ n_kp, int capacity,
+                                                      const int *__restrict__ to_frame, const int *__restrict__ from_frame,
+                                                      double window, unsigned threshold, double ratio,
+                                                      int check_orientation, int *__restrict__ match,
+                                                      unsigned *__restrict__ dist, int *__restrict__ n_matches) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lk_lds[];
   unsigned long long *claim = reinterpret_cast<unsigned long long *>(lk_lds);  // [capacity] per compacted 'from'
   int *to_list = reinterpret_cast<int *>(claim + capacity);
   int *from_list = to_list + capacity;
   int *mj = from_list + capacity;                             // per compacted 'to': compacted 'from' or -1
   unsigned *md = reinterpret_cast<unsigned *>(mj + capacity);
-  __shared__ int s_wtot[4];
+  __shared__ int s_wtot[LK_NT / 64];
   __shared__ int total;
-  const int p = blockIdx.x;
+  const int p = blockIdx.x, tid = threadIdx.x;
   const int ft = to_frame[p], ff = from_frame[p];
   const int n_to = usable_count(n_kp[ft], capacity), n_from = usable_count(n_kp[ff], capacity);
   const orbgpu_keypoint *kt = kp + (size_t)ft * capacity, *kf = kp + (size_t)ff * capacity;
   int *m = match + (size_t)p * capacity;
   unsigned *dd = dist + (size_t)p * capacity;
-  for (int i = threadIdx.x; i < capacity; i += 256) {
+  for (int i = tid; i < capacity; i += LK_NT) {
     m[i] = -1;
     dd[i] = 0;
     claim[i] = ~0ull;
   }
-  if (threadIdx.x == 0) total = 0;
+  if (tid == 0) total = 0;
   // AreaToIterator visits id 0 whatever its level, later ids only when level == 0
-  const int n_to0 = block_compact_list(n_to, to_list, s_wtot, [&](int i) { return i == 0 || kt[i].level == 0; });
-  const int n_from0 = block_compact_list(n_from, from_list, s_wtot, [&](int j) { return kf[j].level == 0; });
+  const int n_to0 = block_compact_list<LK_NT>(n_to, to_list, s_wtot, [&](int i) { return i == 0 || kt[i].level == 0; });
+  const int n_from0 = block_compact_list<LK_NT>(n_from, from_list, s_wtot, [&](int j) { return kf[j].level == 0; });
   const uint4 *__restrict__ fdesc = reinterpret_cast<const uint4 *>(desc + (size_t)ff * capacity * 32);
   // the compacted 'from' set is staged through LDS 256 candidates at a time (descriptor + position), so the scan reads
-  // wave-uniform LDS addresses (broadcast) instead of chasing list index -> descriptor through memory per candidate
+  // wave-uniform LDS addresses (broadcast) instead of chasing list index -> descriptor through memory per candidate.
+  // Thread (group gq = tid / 256, slot tid % 256): 'to' slot s0 + tid % 256 against candidates gq, gq + LK_G, ... of the
+  // chunk; the groups' (best, second) pairs are merged through LDS
   __shared__ uint4 s_fdesc[256][2];
   __shared__ double2 s_fxy[256];
+  __shared__ uint2 s_part[LK_G - 1][256];
+  const int gq = tid >> 8, sl = tid & 255;
   for (int s0 = 0; s0 < n_to0; s0 += 256) {
-    const int slot = s0 + threadIdx.x;
+    const int slot = s0 + sl;
     const int ti = to_list[min(slot, n_to0 - 1)];
     const orbgpu_keypoint k = kt[ti];
     const uint4 *td = reinterpret_cast<const uint4 *>(desc + ((size_t)ft * capacity + ti) * 32);
@@ -1041,15 +1054,15 @@ __global__ __launch_bounds__(256) void k_link_fused(const orbgpu_keypoint *__res
     for (int c0 = 0; c0 < n_from0; c0 += 256) {
       const int nc = min(256, n_from0 - c0);
       __syncthreads();  // the previous chunk has been consumed
-      if ((int)threadIdx.x < nc) {
-        const int j = from_list[c0 + threadIdx.x];
-        s_fdesc[threadIdx.x][0] = fdesc[2 * j];
-        s_fdesc[threadIdx.x][1] = fdesc[2 * j + 1];
-        s_fxy[threadIdx.x] = make_double2(kf[j].x, kf[j].y);
+      if (tid < nc) {
+        const int j = from_list[c0 + tid];
+        s_fdesc[tid][0] = fdesc[2 * j];
+        s_fdesc[tid][1] = fdesc[2 * j + 1];
+        s_fxy[tid] = make_double2(kf[j].x, kf[j].y);
       }
       __syncthreads();
 #pragma unroll 4
-      for (int c = 0; c < nc; c++) {
+      for (int c = gq; c < nc; c += LK_G) {
         const uint4 a = s_fdesc[c][0], b = s_fdesc[c][1];
         const double2 fxy = s_fxy[c];
         unsigned key = (hamming8(t, a, b) << IDX_BITS) | (unsigned)(c0 + c);
@@ -1060,18 +1073,24 @@ __global__ __launch_bounds__(256) void k_link_fused(const orbgpu_keypoint *__res
         best = min(best, key);
       }
     }
-    if (slot < n_to0) {
-      unsigned d = 0;
-      const int cm = snn_accept(best, second, threshold, ratio, d);
-      mj[slot] = cm;
-      md[slot] = d;
-      dd[ti] = d;
-      if (cm >= 0) atomicMin(&claim[cm], ((unsigned long long)d << 32) | (unsigned)ti);
+    if (gq > 0) s_part[gq - 1][sl] = make_uint2(best, second);
+    __syncthreads();
+    if (gq == 0) {
+#pragma unroll
+      for (int q = 0; q < LK_G - 1; q++) merge_keys(best, second, s_part[q][sl].x, s_part[q][sl].y);
+      if (slot < n_to0) {
+        unsigned d = 0;
+        const int cm = snn_accept(best, second, threshold, ratio, d);
+        mj[slot] = cm;
+        md[slot] = d;
+        dd[ti] = d;
+        if (cm >= 0) atomicMin(&claim[cm], ((unsigned long long)d << 32) | (unsigned)ti);
+      }
     }
   }
   __syncthreads();
   int cnt = 0;
-  for (int slot = threadIdx.x; slot < n_to0; slot += 256) {
+  for (int slot = tid; slot < n_to0; slot += LK_NT) {
     const int cm = mj[slot];
     const int ti = to_list[slot];
     if (cm >= 0 && claim[cm] == (((unsigned long long)md[slot] << 32) | (unsigned)ti)) {
@@ -1082,7 +1101,7 @@ __global__ __launch_bounds__(256) void k_link_fused(const orbgpu_keypoint *__res
   if (cnt) atomicAdd(&total, cnt);
   __syncthreads();  // also orders this block's global writes to m[] before the filter reads them
   if (!check_orientation) {
-    if (threadIdx.x == 0) n_matches[p] = total;
+    if (tid == 0) n_matches[p] = total;
     return;
   }
   rotation_filter_block(
@@ -1471,8 +1490,8 @@ void launch_match_frames(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp, const
                          int capacity, const int *d_to_frame, const int *d_from_frame, int n_pairs, uint64_t window,
                          unsigned threshold, double ratio, int check_orientation, int *d_match, unsigned *d_dist,
                          int *d_n_matches) {
-  if (link_fused_lds_bytes(capacity) + 13 * 1024 <= 64 * 1024) {  // + the kernel's static staging buffers
-    hipLaunchKernelGGL(k_link_fused, dim3(n_pairs), dim3(256), link_fused_lds_bytes(capacity), c->stream, d_kp, d_desc, d_n,
+  if (link_fused_lds_bytes(capacity) + 20 * 1024 <= 64 * 1024) {  // + the kernel's static staging / merge buffers
+    hipLaunchKernelGGL(k_link_fused, dim3(n_pairs), dim3(LK_NT), link_fused_lds_bytes(capacity), c->stream, d_kp, d_desc, d_n,
                        capacity, d_to_frame, d_from_frame, (double)window, std::min(threshold, 256u), ratio,
                        check_orientation, d_match, d_dist, d_n_matches);
     return;
