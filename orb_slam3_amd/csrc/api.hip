@@ -229,10 +229,19 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     const bool timed = s == 0 && ctx->stage_timing;  // the stage timers follow slice 0
     const bool timed_fast = s == 0;                  // the FAST kernel (the roofline kernel) is always bracketed
     if (s > 0) HIP_TRY(hipStreamWaitEvent(fs.stream, ev[0], 0));  // fork: after everything already on the context's stream
-    for (int l = 1; l < L; l++) launch_pyramid_level(ctx, fs, l);
+    const int head = ctx->fast_head_levels;
+    for (int l = 1; l < head; l++) launch_pyramid_level(ctx, fs, l);
+    if (head < L) {  // the last levels on the slice's second stream (idle until the blur), beside the first FAST launch
+      HIP_TRY(hipEventRecord(sev[3], fs.stream));
+      HIP_TRY(hipStreamWaitEvent(fb.stream, sev[3], 0));
+      for (int l = head; l < L; l++) launch_pyramid_level(ctx, fb, l);
+      launch_fast_cells(ctx, fb, nullptr, 1);  // their FAST groups too: a small, latency-bound launch (50 us by itself)
+      HIP_TRY(hipEventRecord(sev[4], fb.stream));
+    }
     if (timed_fast) HIP_TRY(hipEventRecord(ev[1], fs.stream));
-    launch_fast_cells(ctx, fs, nullptr);
+    launch_fast_cells(ctx, fs, nullptr, head < L ? 0 : -1);
     if (timed_fast) HIP_TRY(hipEventRecord(ev[2], fs.stream));
+    if (head < L) HIP_TRY(hipStreamWaitEvent(fs.stream, sev[4], 0));
     HIP_TRY(hipEventRecord(sev[0], fs.stream));
     // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
     // dependent rounds in levels x frames workgroups and leaves most of the chip idle
@@ -416,6 +425,16 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       std::vector<short> groups;
       ctx->n_fast_groups = build_fast_groups(g, groups);
       for (int l = 0; l < g.levels; l++) ctx->fast_lds_rows = std::max(ctx->fast_lds_rows, g.lv[l].hcell);
+      // ORBGPU_FAST_SPLIT=1 (opt-in): the last three levels (6 % of the pixels of a 1.2 pyramid, but three dependent,
+      // latency-bound resize launches) are built on the slice's second stream beside the FAST launch of the levels
+      // before them, and scored there in a small launch of their own.  Measured on the 256-frame 640x480 batch: step
+      // 1.038 -> 1.02 ms, but the big FAST launch stretches from 0.335 to 0.358 ms beside that chain, so the per-kernel
+      // numbers (stage times, the roofline kernel's launch duration) stop describing the kernels by themselves
+      const char *fsp = std::getenv("ORBGPU_FAST_SPLIT");
+      ctx->fast_head_levels = (g.levels >= 5 && fsp && fsp[0] == '1') ? g.levels - 3 : g.levels;
+      ctx->n_fast_groups_head = 0;
+      for (size_t q = 0; q < groups.size(); q += 4)
+        if (groups[q] < ctx->fast_head_levels) ctx->n_fast_groups_head++;
       HIP_TRY(dmalloc(&ctx->d_fast_groups, groups.size()));
       HIP_TRY(hipMemcpy(ctx->d_fast_groups, groups.data(), groups.size() * sizeof(short), hipMemcpyHostToDevice));
     }

@@ -128,7 +128,9 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   return v;
 }
 
-template <bool DUMP>
+// PART only names the instantiation: 0 = the launch the roofline is quoted on (all levels, or the large ones), 1 = the
+// small launch for the last pyramid levels, which are built beside launch 0 (profilers keep the two apart by name)
+template <bool DUMP, int PART = 0>
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, DeviceGeom g,
                                                     const FastGroup *__restrict__ groups, int groups_per_frame,
                                                     CellEntry *__restrict__ cells, unsigned *__restrict__ cands,
@@ -426,19 +428,26 @@ int build_fast_groups(const DeviceGeom &g, std::vector<short> &table) {
   return (int)(table.size() / 4);
 }
 
-void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump) {
+// part: -1 = every group in one launch, 0 = the groups of levels < fast_head_levels, 1 = the rest
+void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, int part) {
   const DeviceGeom &g = c->geom;
-  dim3 grid(c->n_fast_groups * xcd_frames(fs.n));
-  const FastGroup *groups = reinterpret_cast<const FastGroup *>(c->d_fast_groups);
+  const int first = part == 1 ? c->n_fast_groups_head : 0;
+  const int count = part == 0 ? c->n_fast_groups_head : c->n_fast_groups - first;
+  if (count <= 0) return;
+  dim3 grid(count * xcd_frames(fs.n));
+  const FastGroup *groups = reinterpret_cast<const FastGroup *>(c->d_fast_groups) + first;
   const size_t lds = fast_cells_lds_bytes(c->fast_lds_rows);
   const uint8_t *pyr = c->d_pyr + (size_t)fs.f0 * g.frame_bytes;
   CellEntry *cells = c->d_cells + (size_t)fs.f0 * g.cells_per_frame;
   unsigned *cands = c->d_cands + (size_t)fs.f0 * g.cands_per_frame;
   if (score_dump)
-    hipLaunchKernelGGL(k_fast_cells<true>, grid, dim3(256), lds, fs.stream, pyr, g, groups, c->n_fast_groups, cells, cands,
+    hipLaunchKernelGGL((k_fast_cells<true, 0>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
                        fs.n, slice_lvl0(c, fs), c->fast_lds_rows, score_dump);
+  else if (part == 1)
+    hipLaunchKernelGGL((k_fast_cells<false, 1>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
+                       fs.n, slice_lvl0(c, fs), c->fast_lds_rows, (uint8_t *)nullptr);
   else
-    hipLaunchKernelGGL(k_fast_cells<false>, grid, dim3(256), lds, fs.stream, pyr, g, groups, c->n_fast_groups, cells, cands,
+    hipLaunchKernelGGL((k_fast_cells<false, 0>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
                        fs.n, slice_lvl0(c, fs), c->fast_lds_rows, (uint8_t *)nullptr);
 }
 

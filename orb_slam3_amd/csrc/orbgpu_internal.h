@@ -103,7 +103,7 @@ struct orbgpu_ctx {
   static constexpr int MAX_SLICES = 4;
   hipStream_t slice_stream[MAX_SLICES]{};  // slices 1.. of a batch (slice 0 runs on `stream`)
   hipStream_t slice_blur[MAX_SLICES]{};    // the blur of a slice runs beside its (latency-bound) quadtree kernel
-  hipEvent_t slice_ev[MAX_SLICES][3]{};    // fork / blur-may-start / slice-done
+  hipEvent_t slice_ev[MAX_SLICES][5]{};    // fork / blur-may-start / slice-done
   std::mutex mu;
   std::string err;
 
@@ -115,6 +115,8 @@ struct orbgpu_ctx {
   bool no_zero_copy = false;      // ORBGPU_NO_ZERO_COPY=1: always copy level 0 into the slab (cross-check path)
   short *d_fast_groups = nullptr; // FastGroup table of k_fast_cells (level, cell row, first cell, cells), one frame's worth
   int n_fast_groups = 0;
+  int fast_head_levels = 0;       // levels whose FAST groups form the first launch (the rest: built and scored beside it)
+  int n_fast_groups_head = 0;     // groups of those levels (the table is level-major)
   short *d_blur_tiles = nullptr;  // (level, x0, y0, 0) per blur tile of one frame
   int fast_lds_rows = 0;          // tallest cell of any level: sizes the dynamic LDS of k_fast_cells
   int n_slices = 1;               // slices a batch is cut into (ORBGPU_SLICES overrides)
@@ -186,7 +188,7 @@ void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level);
 // fused FAST score + cell NMS (k_fast.hip); score_dump != nullptr: also scatter the non-zero scores into that slab
 // (laid out like the slice: its frame 0 is frame f0 of the batch)
 int build_fast_groups(const DeviceGeom &g, std::vector<short> &table);
-void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump);
+void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, int part = -1);
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs);
 void launch_orient(const orbgpu_ctx *c, FrameSlice fs);
 void launch_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
