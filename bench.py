@@ -360,6 +360,22 @@ def main():
                 "stage_ms_source": "fast_score and extract_ms_per_batch: HIP events inside the timed steps; the other stages: "
                                    "a separate pass right after them with every stage boundary recorded "
                                    "(orbgpu_set_stage_timing; the extra events cost ~2.5 % of a step)"}
+    # what this box's HBM gives a plain device-to-device copy of a pyramid-sized buffer (read + write), for scale: the
+    # contractual fractions above are against the nominal 8 TB/s
+    if world == 1:
+        n_copy = P * B
+        c_src = torch.empty(n_copy, dtype=torch.uint8, device=dev).fill_(7)
+        c_dst = torch.empty_like(c_src)
+        c_dst.copy_(c_src)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            c_dst.copy_(c_src)
+        torch.cuda.synchronize()
+        copy_gbps = 2 * n_copy * 20 / (time.perf_counter() - t1) / 1e9
+        pipeline["hbm_copy_measured_GBps"] = round(copy_gbps, 1)
+        pipeline["frac_of_measured_copy_rate"] = round(pipeline["achieved_GBps"] / copy_gbps, 4)
+        del c_src, c_dst
     # SURVEY 8d's decomposition of A per stage, each against its own stage time (the quadtree has no algorithmic bytes of
     # its own: its traffic is implementation intermediates; the orientation kernel runs beside the blur, off the
     # critical path)
