@@ -94,6 +94,13 @@ def test_large_64_frames_1080p(oracle):
     assert n.mean() > 4500 and nm.mean() > 300
 
 
+def test_batch_4k_frames(oracle):
+    """BASELINE.json configs[2], 3840x2160 / 5000 keypoints: a 4-frame device batch and its 3 links (grid link path, 1024-thread
+    quadtree workgroups) against the oracle."""
+    n, nm = _extract_and_link(oracle, 3840, 2160, 5000, 4, 4, 1237)
+    assert n.mean() > 4500 and nm.mean() > 200
+
+
 def test_large_capacity_link_grid_equals_plain_scan(oracle):
     """Above the fused link kernel's capacity orbgpu_match_frames_device bins the level-0 rows by the 64 x 48 search grid
     (k_link_grid); ORBGPU_LINK_SCAN=1 keeps the plain predicated scan.  Same matches, distances and counts, on pairs that
