@@ -242,7 +242,10 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     launch_fast_cells(ctx, fs, nullptr, head < L ? 0 : -1);
     if (timed_fast) HIP_TRY(hipEventRecord(ev[2], fs.stream));
     if (head < L) HIP_TRY(hipStreamWaitEvent(fs.stream, sev[4], 0));
-    HIP_TRY(hipEventRecord(sev[0], fs.stream));
+    // the blur's fork point: the FAST kernel's end event when it has just been recorded (one event between two kernels
+    // of the critical path instead of two)
+    hipEvent_t fork_ev = (timed_fast && head == L) ? ev[2] : sev[0];
+    if (fork_ev == sev[0]) HIP_TRY(hipEventRecord(sev[0], fs.stream));
     // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
     // dependent rounds in levels x frames workgroups and leaves most of the chip idle
     // (enqueued after the quadtree so that the quadtree's workgroups are placed first and the blur fills the rest)
@@ -251,7 +254,7 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     if (timed) HIP_TRY(hipEventRecord(ev[4], fs.stream));
     launch_orient(ctx, fs);  // IC_Angle needs the unblurred levels only: beside the blur, behind the quadtree
     if (timed) HIP_TRY(hipEventRecord(ev[3], fs.stream));
-    HIP_TRY(hipStreamWaitEvent(fb.stream, sev[0], 0));
+    HIP_TRY(hipStreamWaitEvent(fb.stream, fork_ev, 0));
     if (timed) HIP_TRY(hipEventRecord(ev[7], fb.stream));
     launch_blur(ctx, fb);
     if (timed) HIP_TRY(hipEventRecord(ev[8], fb.stream));
