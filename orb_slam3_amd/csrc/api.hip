@@ -269,7 +269,6 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     }
   }
   HIP_TRY(hipEventRecord(ev[9], ctx->stream));  // every slice has finished
-  HIP_TRY(hipMemcpyAsync(ctx->h_error_flag, ctx->d_error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipGetLastError());
   ctx->ev_full[ctx->ev_head] = ctx->stage_timing;
   ctx->ev_head = (ctx->ev_head + 1) % ORBGPU_EV_SETS;
@@ -302,11 +301,9 @@ int finish_pipeline(orbgpu_ctx *ctx) {
     }
     for (int i = 0; i < 7; i++) ctx->stage_ms[i] = acc[i] / (float)n;
   }
-  if (*ctx->h_error_flag != 0) {  // copied back after every pipeline run and every grid matcher call
+  if (*(volatile int *)ctx->h_error_flag != 0) {  // written by the kernels themselves (mapped host memory)
     const int code = *ctx->h_error_flag;
-    *ctx->h_error_flag = 0;
-    HIP_TRY(hipMemsetAsync(ctx->d_error_flag, 0, sizeof(int), ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *ctx->h_error_flag = 0;  // the stream is idle: finish_pipeline has just synchronised it
     if (code == ORBGPU_ERR_OUT_CAPACITY)
       return fail(ctx, ORBGPU_E_CAPACITY, "a frame has more keypoints than the caller's capacity: that frame was not written "
                                           "(its entry of n_out holds the count it needs)");
@@ -462,10 +459,11 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(dmalloc(&ctx->d_cands_tmp, B * g.cands_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cell_prefix, B * g.cells_per_frame));
     if (qt_node_scratch) HIP_TRY(dmalloc(&ctx->d_qt_nodes, qt_node_scratch));
-    HIP_TRY(dmalloc(&ctx->d_error_flag, 1));
-    HIP_TRY(hipMemset(ctx->d_error_flag, 0, sizeof(int)));
-    HIP_TRY(hmalloc(&ctx->h_error_flag, 1));
+    // the error flag lives in pinned host memory that the device writes directly (only ever in the error case): no copy
+    // per call -- a device-to-host copy of one int is a blit kernel of its own, 12 us between two kernels
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_error_flag), sizeof(int), hipHostMallocMapped));
     *ctx->h_error_flag = 0;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->d_error_flag), ctx->h_error_flag, 0));
     HIP_TRY(dmalloc(&ctx->d_kp_xy, B * g.kps_per_frame));
     HIP_TRY(dmalloc(&ctx->d_kp_count, B * g.levels));
     HIP_TRY(dmalloc(&ctx->d_kp_angle, B * g.kps_per_frame));
@@ -492,7 +490,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count, ctx->d_kp_angle,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes,
-                   ctx->d_error_flag, ctx->d_fast_groups, ctx->d_blur_tiles};
+                   ctx->d_fast_groups, ctx->d_blur_tiles};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
   void *hptrs[] = {ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};
@@ -917,7 +915,6 @@ int orbgpu_grid_build_device(orbgpu_ctx *ctx, const double *d_xy, const int32_t 
   if (rc) return rc;
   launch_grid_build(ctx, d_xy, d_ranges, n_ranges, max_count, image_width, image_height, d_cell_start, d_items,
                     ctx->d_match_scratch);
-  HIP_TRY(hipMemcpyAsync(ctx->h_error_flag, ctx->d_error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipGetLastError());
   return ORBGPU_OK;
 }
@@ -949,7 +946,6 @@ int orbgpu_match_window_grid_segments_device(orbgpu_ctx *ctx, const orbgpu_windo
   launch_match_grid_segments(ctx, *a, d_segments, n_segments, max_to_count, std::max(max_from_count, 1), a->n_from,
                              image_width, image_height, d_from_idx_per_to, reinterpret_cast<unsigned *>(d_dist),
                              ctx->d_match_scratch);
-  HIP_TRY(hipMemcpyAsync(ctx->h_error_flag, ctx->d_error_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipGetLastError());
   return ORBGPU_OK;
 }

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * KPB) void k_describe(const uint8_t *__restrict
     out_n[f] = total;
     // the frame does not fit the caller's arrays: nothing of it is written, the count says how much room it needs, and
     // the context's error flag makes the next orbgpu_synchronize / orbgpu_stage_times return ORBGPU_E_CAPACITY
-    if (total > capacity) atomicExch(error_flag, ORBGPU_ERR_OUT_CAPACITY);
+    if (total > capacity) *(volatile int *)error_flag = ORBGPU_ERR_OUT_CAPACITY;  // mapped host memory: a plain store
   }
   bool any_valid = false;
 #pragma unroll

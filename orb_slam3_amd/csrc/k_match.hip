@@ -504,7 +504,7 @@ __device__ __forceinline__ void grid_build_body(const GridBuildArgs &a, const Gr
   const int begin = a.ranges ? a.ranges[r * a.range_stride + a.range_off] : a.one[a.range_off];
   int count = a.ranges ? a.ranges[r * a.range_stride + a.range_off + 1] : a.one[a.range_off + 1];
   if (count > a.out_stride) {  // the caller's max count was too small: stay inside this range's rows and say so
-    if (threadIdx.x == 0 && a.error_flag) atomicExch(a.error_flag, ORBGPU_ERR_SEGMENT_SIZE);
+    if (threadIdx.x == 0 && a.error_flag) *(volatile int *)a.error_flag = ORBGPU_ERR_SEGMENT_SIZE;
     count = a.out_stride;
   }
   const size_t out = (size_t)r * a.out_stride;

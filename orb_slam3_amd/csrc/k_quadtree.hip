@@ -478,7 +478,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     const u64 tot = block_excl_scan<NT>(S.pre, Sz, wsum);
     const int ct = (int)f0(tot), kt = (int)f1(tot), mt = (int)f2(tot);
     if (ct + kt > cap) {  // cannot happen: the list never exceeds max(nF + 3, 4 nIni)
-      if (tid == 0) atomicExch(a.error_flag, 1);
+      if (tid == 0) *(volatile int *)a.error_flag = 1;
       Sz = 0;
       break;
     }
@@ -561,7 +561,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     __syncthreads();
     const int kt = (int)block_excl_scan<NT>(S.pre2, Sz, wsum);
     if (ct + kt > cap) {
-      if (tid == 0) atomicExch(a.error_flag, 1);
+      if (tid == 0) *(volatile int *)a.error_flag = 1;
       Sz = 0;
       break;
     }
@@ -583,7 +583,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
   // ---- best point of each node: first maximum, strict > (:486-501) ----
   short2 *out = a.kp_xy + (size_t)f * g.kps_per_frame + L.kp_off;
   if (Sz > L.kp_cap) {
-    if (tid == 0) atomicExch(a.error_flag, 3);
+    if (tid == 0) *(volatile int *)a.error_flag = 3;
     Sz = 0;
   }
   for (int i = tid; i < Sz; i += NT) {
