@@ -439,10 +439,10 @@ int orbgpu_bowdb_query(orbgpu_bowdb *db, const uint32_t *q_words, const double *
  * (orbgpu_set_batch_slices) [0]..[5] are the kernels of slice 0 -- its share of the frames, running beside the other
  * slices -- and [6] still spans the whole batch.  Used by bench.py for the roofline line. */
 int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms7);
-/* Which stage boundaries an extract call records.  0 (the default): only what costs nothing to speak of -- the start of
- * the call, the FAST kernel's two ends and the end of the call, so orbgpu_stage_times fills [0], [1] and [6] and leaves
- * the rest 0.  1: every boundary; each extra event is a few microseconds between two kernels (about 2.5 % of a
- * 256-frame 640x480 batch), which is why it is a switch. */
+/* Which stage boundaries an extract call records.  An event between two kernels costs 6-7 us of stream time, so:
+ * 0 (the default): only the FAST kernel's two ends (the kernel the roofline is quoted on) -- orbgpu_stage_times fills
+ * [1] and leaves the rest 0; time the whole call from the host.  1: every boundary and the call's two ends (about 3 %
+ * of a 256-frame 640x480 batch), which is why it is a switch. */
 int orbgpu_set_stage_timing(orbgpu_ctx *ctx, int32_t all_stages);
 /* Runs a register-resident XOR + v_bcnt_u32_b32 loop and returns descriptor pairs per second: the
  * measured popcount ceiling that BASELINE.md asks to report next to the nominal one. */

@@ -220,7 +220,9 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   hipEvent_t *ev = ctx->ev[ctx->ev_head];
   int n_slices = ctx->n_slices > 0 ? ctx->n_slices : 1;
   n_slices = std::max(1, std::min(std::min(n_slices, (int)orbgpu_ctx::MAX_SLICES), n_frames));
-  HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+  // an event between two kernels of a stream costs 6-7 us of stream time: by default only the FAST kernel is bracketed
+  const bool ends = ctx->stage_timing || n_slices > 1;  // ev[0]: start of the call (and the slices' fork), ev[9]: its end
+  if (ends) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
   for (int s = 0; s < n_slices; s++) {
     const int f0 = (int)((long long)n_frames * s / n_slices), f1 = (int)((long long)n_frames * (s + 1) / n_slices);
     const FrameSlice fs{f0, f1 - f0, s == 0 ? ctx->stream : ctx->slice_stream[s]};
@@ -268,7 +270,7 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
       HIP_TRY(hipStreamWaitEvent(ctx->stream, sev[2], 0));
     }
   }
-  HIP_TRY(hipEventRecord(ev[9], ctx->stream));  // every slice has finished
+  if (ctx->stage_timing) HIP_TRY(hipEventRecord(ev[9], ctx->stream));  // every slice has finished
   HIP_TRY(hipGetLastError());
   ctx->ev_full[ctx->ev_head] = ctx->stage_timing;
   ctx->ev_head = (ctx->ev_head + 1) % ORBGPU_EV_SETS;
@@ -289,15 +291,15 @@ int finish_pipeline(orbgpu_ctx *ctx) {
     float acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int k = 1; k <= n; k++) {
       hipEvent_t *ev = ctx->ev[(ctx->ev_head - k + ORBGPU_EV_SETS) % ORBGPU_EV_SETS];
-      acc[0] += elapsed(ev[0], ev[1]);
-      acc[1] += elapsed(ev[1], ev[2]);  // FAST score + cells; [2] (cells) has no kernel of its own any more
+      acc[1] += elapsed(ev[1], ev[2]);  // FAST score + cells
       if (ctx->ev_full[(ctx->ev_head - k + ORBGPU_EV_SETS) % ORBGPU_EV_SETS]) {
+        acc[0] += elapsed(ev[0], ev[1]);
+        acc[6] += elapsed(ev[0], ev[9]);
         acc[2] += elapsed(ev[4], ev[3]);  // orientation, behind the quadtree and beside the blur
         acc[3] += elapsed(ev[2], ev[4]);
         acc[4] += elapsed(ev[7], ev[8]);  // blur, on its own stream (overlaps the quadtree stage)
         acc[5] += elapsed(ev[5], ev[6]);
       }
-      acc[6] += elapsed(ev[0], ev[9]);
     }
     for (int i = 0; i < 7; i++) ctx->stage_ms[i] = acc[i] / (float)n;
   }
