@@ -280,6 +280,10 @@ def main():
     stt = fe.stage_times()
     fe.set_stage_timing(False)
     st = np.array([stt[k] for k in ("pyramid", "fast_score", "orient", "quadtree", "blur", "describe", "total")])
+    # level 0 needs no pyramid: by default its FAST groups are a launch of their own (same kernel) on the second stream
+    # beside the resize chain, and the launch on the critical path -- the one timed here -- covers the levels >= 1
+    fast_l0_ms = stt["fast_level0"]
+    early_l0 = fast_l0_ms > 0
     st[1], st[6] = fast_ms_timed, extract_ms_timed    # what the roofline and pipeline objects use: the timed region's
     # the link matcher alone, outside the timed region (informational)
     link_ms = 0.0
@@ -344,22 +348,28 @@ def main():
     n_kp = d_n.cpu().numpy()
     n_matches = d_nm.cpu().numpy()[:n_pairs]
     # ---- roofline of the dominant extraction kernel (FAST score map, one launch per batch) --------------
-    # algorithmic bytes per launch = P bytes read per frame (SURVEY 8d "FAST (P read)") x frames per launch
+    # algorithmic bytes per launch = the pixels the launch reads per frame (SURVEY 8d "FAST (P read)": all P, or P - px0
+    # when level 0 has its own launch beside the pyramid) x frames per launch
     fast_s = st[1] * 1e-3
     hbm_peak = 8000.0
-    fast_gbs = P * B / fast_s / 1e9 if fast_s > 0 else 0.0
+    P_fast = P - g.w[0] * g.h[0] if early_l0 else P
+    fast_kernel = "k_fast_cells<false,0>" if early_l0 else "k_fast_cells"
+    fast_gbs = P_fast * B / fast_s / 1e9 if fast_s > 0 else 0.0
     # HBM-side bytes per launch from the committed counter passes (tools/profile_round.sh -> profiles/): valid for the
     # default workload only, null otherwise
     traffic, traffic_src, sq = None, None, {}
     tfile = ROOT / "profiles" / "r2_hbm_traffic.json"
     if tfile.exists() and headline:
         tj = json.loads(tfile.read_text())
-        traffic = tj["kernels"].get("k_fast_cells", {}).get("hbm_bytes")
+        traffic = tj["kernels"].get(fast_kernel, {}).get("hbm_bytes")
         traffic_src = "profiles/r2_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this workload)"
         sq = tj.get("sq_counters_per_launch", {})
-    roofline = {"bound": "hbm", "kernel": "k_fast_cells", "achieved": round(fast_gbs, 2), "peak": hbm_peak,
+    roofline = {"bound": "hbm", "kernel": fast_kernel, "achieved": round(fast_gbs, 2), "peak": hbm_peak,
                 "unit": "GB/s", "frac": round(fast_gbs / hbm_peak, 5), "traffic": traffic,
-                "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P * B, "traffic_source": traffic_src,
+                "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P_fast * B, "traffic_source": traffic_src,
+                "launch": ("pyramid levels >= 1 of every frame, alone on the device; level 0's groups are a second launch of "
+                           "the same kernel (k_fast_cells<false,1>, pipeline.fast_level0) that needs no pyramid and runs "
+                           "beside the resize chain") if early_l0 else "all pyramid levels of every frame",
                 "limiter": "instruction issue, not HBM: the kernel (FAST score + per-cell NMS, fallback and compaction, fused) "
                            "issues about one vector instruction per clock per CU, the measured ceiling of its mix "
                            "(profiles/r2_hbm_traffic.json sq_counters_per_launch, profiles/r2_valu_rate.txt)"}
@@ -372,6 +382,9 @@ def main():
                 "frac_of_8TBps": round(A * B / ext_s / 1e9 / hbm_peak, 5) if ext_s > 0 else 0.0,
                 "stage_ms": {k: round(float(v), 4) for k, v in zip(("pyramid", "fast_score", "orient", "quadtree", "blur", "describe"), st[:6])},
                 "link_match_ms_per_batch": round(link_ms, 3),
+                "fast_level0": ({"ms": round(float(fast_l0_ms), 4), "beside": "pyramid (second stream)",
+                                 "algorithmic_GBps": round(g.w[0] * g.h[0] * B / (fast_l0_ms * 1e-3) / 1e9, 1)}
+                                if early_l0 else None),
                 "stage_ms_source": "fast_score: HIP events around the kernel inside the timed steps; extract_ms_per_batch: host "
                                    "clock over a loop of extract calls alone, right after them; the other stages: a third "
                                    "pass with every stage boundary recorded (orbgpu_set_stage_timing; the extra events cost "
@@ -396,7 +409,7 @@ def main():
     # its own: its traffic is implementation intermediates; the orientation kernel runs beside the blur, off the
     # critical path)
     px0, px7 = g.w[0] * g.h[0], g.w[g.levels - 1] * g.h[g.levels - 1]
-    stage_bytes = {"pyramid": 2 * P - px0 - px7, "fast_score": P, "blur": 2 * P,
+    stage_bytes = {"pyramid": 2 * P - px0 - px7, "fast_score": P_fast, "blur": 2 * P,
                    "orient": 961 * NF, "describe": (961 + 56) * NF}
     pipeline["stage_algorithmic_GBps"] = {
         k: round(stage_bytes[k] * B / (pipeline["stage_ms"][k] * 1e-3) / 1e9, 1) if pipeline["stage_ms"][k] > 0 else 0.0
@@ -406,7 +419,7 @@ def main():
     # their instruction mix (tools/valu_rate.hip: ~0.9 for min/max/perm/dot/mad24, ~1.6 for add/and/shift).  Instruction
     # counts per launch come from the committed counter pass (they do not change from run to run), times from this run
     if sq:
-        stage_of = {"k_resize_level": ("pyramid", g.levels - 1), "k_fast_cells": ("fast_score", 1), "k_quadtree": ("quadtree", 1),
+        stage_of = {"k_resize_level": ("pyramid", g.levels - 1), fast_kernel: ("fast_score", 1), "k_quadtree": ("quadtree", 1),
                     "k_blur": ("blur", 1), "k_orient": ("orient", 1), "k_describe": ("describe", 1)}
         vi = {}
         for kname, (stage, launches) in stage_of.items():

@@ -434,11 +434,14 @@ int orbgpu_bowdb_query(orbgpu_bowdb *db, const uint32_t *q_words, const double *
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-stage GPU time in milliseconds (HIP events on the context's stream), averaged over the extract calls
  * enqueued since the last orbgpu_synchronize / orbgpu_stage_times (at most the last 32); waits for the stream.
- * [0] pyramid [1] FAST score + cell NMS / fallback / compaction (one fused kernel) [2] orientation (its kernel runs behind
- * the quadtree and beside the blur, off the critical path) [3] quadtree [4] blur [5] descriptor [6] total.  With more than one slice per batch
- * (orbgpu_set_batch_slices) [0]..[5] are the kernels of slice 0 -- its share of the frames, running beside the other
- * slices -- and [6] still spans the whole batch.  Used by bench.py for the roofline line. */
-int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms7);
+ * ms8 = 8 floats: [0] pyramid (the resize chain; level 0's FAST launch runs beside it on the second stream)
+ * [1] FAST score + cell NMS / fallback / compaction (one fused kernel) of the levels >= 1 -- the launch on the critical
+ * path, the one the roofline is quoted on [2] orientation (its kernel runs behind the quadtree and beside the blur, off
+ * the critical path) [3] quadtree [4] blur [5] descriptor [6] total [7] the same FAST kernel's launch for level 0 (it
+ * needs no pyramid; 0 when ORBGPU_EARLY_L0=0 puts all levels into launch [1]).  With more than one slice per batch
+ * (orbgpu_set_batch_slices) [0]..[5] and [7] are the kernels of slice 0 -- its share of the frames, running beside the
+ * other slices -- and [6] still spans the whole batch.  Used by bench.py for the roofline line. */
+int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms8);
 /* Which stage boundaries an extract call records.  An event between two kernels costs 6-7 us of stream time, so:
  * 0 (the default): only the FAST kernel's two ends (the kernel the roofline is quoted on) -- orbgpu_stage_times fills
  * [1] and leaves the rest 0; time the whole call from the host.  1: every boundary and the call's two ends (about 3 %

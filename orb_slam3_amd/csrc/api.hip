@@ -231,22 +231,23 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     const bool timed = s == 0 && ctx->stage_timing;  // the stage timers follow slice 0
     const bool timed_fast = s == 0;                  // the FAST kernel (the roofline kernel) is always bracketed
     if (s > 0) HIP_TRY(hipStreamWaitEvent(fs.stream, ev[0], 0));  // fork: after everything already on the context's stream
-    const int head = ctx->fast_head_levels;
-    for (int l = 1; l < head; l++) launch_pyramid_level(ctx, fs, l);
-    if (head < L) {  // the last levels on the slice's second stream (idle until the blur), beside the first FAST launch
-      HIP_TRY(hipEventRecord(sev[3], fs.stream));
+    const bool early = ctx->early_l0;
+    if (early) {  // level 0 needs no pyramid: its FAST groups on the slice's second stream (idle until the blur)
+      HIP_TRY(hipEventRecord(sev[3], fs.stream));  // after everything already on the stream (the caller's images included)
       HIP_TRY(hipStreamWaitEvent(fb.stream, sev[3], 0));
-      for (int l = head; l < L; l++) launch_pyramid_level(ctx, fb, l);
-      launch_fast_cells(ctx, fb, nullptr, 1);  // their FAST groups too: a small, latency-bound launch (50 us by itself)
+      if (timed) HIP_TRY(hipEventRecord(ev[10], fb.stream));
+      launch_fast_cells(ctx, fb, nullptr, 1);
+      if (timed) HIP_TRY(hipEventRecord(ev[11], fb.stream));
       HIP_TRY(hipEventRecord(sev[4], fb.stream));
     }
+    for (int l = 1; l < L; l++) launch_pyramid_level(ctx, fs, l);
     if (timed_fast) HIP_TRY(hipEventRecord(ev[1], fs.stream));
-    launch_fast_cells(ctx, fs, nullptr, head < L ? 0 : -1);
+    launch_fast_cells(ctx, fs, nullptr, early ? 0 : -1);
     if (timed_fast) HIP_TRY(hipEventRecord(ev[2], fs.stream));
-    if (head < L) HIP_TRY(hipStreamWaitEvent(fs.stream, sev[4], 0));
+    if (early) HIP_TRY(hipStreamWaitEvent(fs.stream, sev[4], 0));  // the quadtree needs every level's cells
     // the blur's fork point: the FAST kernel's end event when it has just been recorded (one event between two kernels
     // of the critical path instead of two)
-    hipEvent_t fork_ev = (timed_fast && head == L) ? ev[2] : sev[0];
+    hipEvent_t fork_ev = timed_fast ? ev[2] : sev[0];
     if (fork_ev == sev[0]) HIP_TRY(hipEventRecord(sev[0], fs.stream));
     // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
     // dependent rounds in levels x frames workgroups and leaves most of the chip idle
@@ -288,7 +289,7 @@ int finish_pipeline(orbgpu_ctx *ctx) {
     // stage times: mean over the extract calls enqueued since the last synchronisation (at most ORBGPU_EV_SETS)
     const int n = ctx->ev_pending;
     ctx->ev_pending = 0;
-    float acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 1; k <= n; k++) {
       hipEvent_t *ev = ctx->ev[(ctx->ev_head - k + ORBGPU_EV_SETS) % ORBGPU_EV_SETS];
       acc[1] += elapsed(ev[1], ev[2]);  // FAST score + cells
@@ -299,9 +300,10 @@ int finish_pipeline(orbgpu_ctx *ctx) {
         acc[3] += elapsed(ev[2], ev[4]);
         acc[4] += elapsed(ev[7], ev[8]);  // blur, on its own stream (overlaps the quadtree stage)
         acc[5] += elapsed(ev[5], ev[6]);
+        if (ctx->early_l0) acc[7] += elapsed(ev[10], ev[11]);  // FAST of level 0, on the second stream beside the pyramid
       }
     }
-    for (int i = 0; i < 7; i++) ctx->stage_ms[i] = acc[i] / (float)n;
+    for (int i = 0; i < 8; i++) ctx->stage_ms[i] = acc[i] / (float)n;
   }
   if (*(volatile int *)ctx->h_error_flag != 0) {  // written by the kernels themselves (mapped host memory)
     const int code = *ctx->h_error_flag;
@@ -427,16 +429,14 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       std::vector<short> groups;
       ctx->n_fast_groups = build_fast_groups(g, groups);
       for (int l = 0; l < g.levels; l++) ctx->fast_lds_rows = std::max(ctx->fast_lds_rows, g.lv[l].hcell);
-      // ORBGPU_FAST_SPLIT=1 (opt-in): the last three levels (6 % of the pixels of a 1.2 pyramid, but three dependent,
-      // latency-bound resize launches) are built on the slice's second stream beside the FAST launch of the levels
-      // before them, and scored there in a small launch of their own.  Measured on the 256-frame 640x480 batch: step
-      // 1.038 -> 1.02 ms, but the big FAST launch stretches from 0.335 to 0.358 ms beside that chain, so the per-kernel
-      // numbers (stage times, the roofline kernel's launch duration) stop describing the kernels by themselves
-      const char *fsp = std::getenv("ORBGPU_FAST_SPLIT");
-      ctx->fast_head_levels = (g.levels >= 5 && fsp && fsp[0] == '1') ? g.levels - 3 : g.levels;
-      ctx->n_fast_groups_head = 0;
+      // level 0 needs no pyramid: its FAST groups run on the second stream beside the resize chain (the resize kernels
+      // issue 0.59 vector instructions per clock and CU, the FAST kernel is bound by issue: 256-frame 640x480 batch 1.044 ->
+      // 0.996 ms).  ORBGPU_EARLY_L0=0 puts every group back into one launch behind the pyramid
+      ctx->n_fast_groups_l0 = 0;
       for (size_t q = 0; q < groups.size(); q += 4)
-        if (groups[q] < ctx->fast_head_levels) ctx->n_fast_groups_head++;
+        if (groups[q] == 0) ctx->n_fast_groups_l0++;
+      const char *el0 = std::getenv("ORBGPU_EARLY_L0");
+      ctx->early_l0 = g.levels >= 2 && !(el0 && el0[0] == '0');
       HIP_TRY(dmalloc(&ctx->d_fast_groups, groups.size()));
       HIP_TRY(hipMemcpy(ctx->d_fast_groups, groups.data(), groups.size() * sizeof(short), hipMemcpyHostToDevice));
     }
@@ -1608,12 +1608,12 @@ int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to,
   return ORBGPU_OK;
 }
 
-int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms7) {
-  if (!ctx || !ms7) return ORBGPU_E_INVALID;
+int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms8) {
+  if (!ctx || !ms8) return ORBGPU_E_INVALID;
   std::lock_guard<std::mutex> lock(ctx->mu);
   int rc = finish_pipeline(ctx);
   if (rc) return rc;
-  for (int i = 0; i < 7; i++) ms7[i] = ctx->stage_ms[i];
+  for (int i = 0; i < 8; i++) ms8[i] = ctx->stage_ms[i];
   return ORBGPU_OK;
 }
 

@@ -128,8 +128,8 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   return v;
 }
 
-// PART only names the instantiation: 0 = the launch the roofline is quoted on (all levels, or the large ones), 1 = the
-// small launch for the last pyramid levels, which are built beside launch 0 (profilers keep the two apart by name)
+// PART only names the instantiation: 0 = the launch the roofline is quoted on (levels >= 1, or all levels), 1 = the
+// launch for level 0, which runs on the second stream beside the resize chain (profilers keep the two apart by name)
 template <bool DUMP, int PART = 0>
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, DeviceGeom g,
                                                     const FastGroup *__restrict__ groups, int groups_per_frame,
@@ -428,11 +428,11 @@ int build_fast_groups(const DeviceGeom &g, std::vector<short> &table) {
   return (int)(table.size() / 4);
 }
 
-// part: -1 = every group in one launch, 0 = the groups of levels < fast_head_levels, 1 = the rest
+// part: -1 = every group in one launch, 0 = the groups of levels >= 1, 1 = the groups of level 0 (the table is level-major)
 void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, int part) {
   const DeviceGeom &g = c->geom;
-  const int first = part == 1 ? c->n_fast_groups_head : 0;
-  const int count = part == 0 ? c->n_fast_groups_head : c->n_fast_groups - first;
+  const int first = part == 0 ? c->n_fast_groups_l0 : 0;
+  const int count = part == 1 ? c->n_fast_groups_l0 : c->n_fast_groups - first;
   if (count <= 0) return;
   dim3 grid(count * xcd_frames(fs.n));
   const FastGroup *groups = reinterpret_cast<const FastGroup *>(c->d_fast_groups) + first;

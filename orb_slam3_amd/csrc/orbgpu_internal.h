@@ -115,8 +115,8 @@ struct orbgpu_ctx {
   bool no_zero_copy = false;      // ORBGPU_NO_ZERO_COPY=1: always copy level 0 into the slab (cross-check path)
   short *d_fast_groups = nullptr; // FastGroup table of k_fast_cells (level, cell row, first cell, cells), one frame's worth
   int n_fast_groups = 0;
-  int fast_head_levels = 0;       // levels whose FAST groups form the first launch (the rest: built and scored beside it)
-  int n_fast_groups_head = 0;     // groups of those levels (the table is level-major)
+  int n_fast_groups_l0 = 0;       // groups of level 0 (the table is level-major)
+  bool early_l0 = true;           // level 0's FAST groups on the second stream beside the resize chain (ORBGPU_EARLY_L0=0: off)
   short *d_blur_tiles = nullptr;  // (level, x0, y0, 0) per blur tile of one frame
   int fast_lds_rows = 0;          // tallest cell of any level: sizes the dynamic LDS of k_fast_cells
   int n_slices = 1;               // slices a batch is cut into (ORBGPU_SLICES overrides)
@@ -148,7 +148,7 @@ struct orbgpu_ctx {
   void *d_match_scratch = nullptr;
   size_t match_scratch_bytes = 0;
 
-  hipEvent_t ev[ORBGPU_EV_SETS][10]{};  // stage boundaries of the last ORBGPU_EV_SETS extract calls (ring);
+  hipEvent_t ev[ORBGPU_EV_SETS][12]{};  // stage boundaries of the last ORBGPU_EV_SETS extract calls (ring);
                                        // [7], [8] bracket the blur on its own stream, [9] = all slices joined
   int ev_head = 0, ev_pending = 0;
   bool ev_full[ORBGPU_EV_SETS]{};      // that set holds every stage boundary, not only the FAST kernel's and the total
@@ -157,7 +157,7 @@ struct orbgpu_ctx {
   bool link_plain_scan = false;   // ORBGPU_LINK_SCAN=1: large-capacity links by the plain predicated scan (comparison)
   bool bruteforce_mfma = false;  // exploratory engine of the brute-force matcher (orbgpu_set_bruteforce_engine)
   bool stage_timing = false;           // record every stage boundary (each event costs a few microseconds between kernels)
-  float stage_ms[7]{};
+  float stage_ms[8]{};
   int last_frames = 0;
   int last_feature_count = 0;
   int last_slices = 1;

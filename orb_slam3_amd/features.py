@@ -182,9 +182,10 @@ class ORBFeatureExtractor:
         self._check(self._lib.orbgpu_set_stage_timing(self._h, 1 if all_stages else 0))
 
     def stage_times(self):
-        ms = np.zeros(7, np.float32)
+        ms = np.zeros(8, np.float32)
         self._check(self._lib.orbgpu_stage_times(self._h, _lib.ptr(ms)))
-        return dict(zip(("pyramid", "fast_score", "orient", "quadtree", "blur", "describe", "total"), ms.tolist()))
+        return dict(zip(("pyramid", "fast_score", "orient", "quadtree", "blur", "describe", "total", "fast_level0"),
+                        ms.tolist()))
 
     def popcount_peak(self):
         v = C.c_double(0)

@@ -11,16 +11,29 @@ import collections, csv, glob, json, re, sys
 root, out = sys.argv[1], sys.argv[2]
 
 
+def kname(full):
+    """short kernel name; the two launches of k_fast_cells per extraction (levels >= 1 / level 0) stay apart"""
+    m = re.search(r"\bk_\w+", full)
+    if not m:
+        return None
+    k = m.group(0)
+    t = re.search(r"k_fast_cells<([^>]*)>", full)
+    if k == "k_fast_cells" and t:
+        k += "<" + t.group(1).replace(" ", "") + ">"
+    return k
+
+
+
 def mean_per_kernel(sub, counter):
     acc, n = collections.defaultdict(float), collections.defaultdict(int)
     for f in glob.glob(f"{root}/{sub}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter:
                 continue
-            m = re.search(r"\bk_\w+", row["Kernel_Name"])
-            if m:
-                acc[m.group(0)] += float(row["Counter_Value"])
-                n[m.group(0)] += 1
+            k = kname(row["Kernel_Name"])
+            if k:
+                acc[k] += float(row["Counter_Value"])
+                n[k] += 1
     return {k: acc[k] / n[k] for k in acc}
 
 
@@ -44,10 +57,10 @@ sq = collections.defaultdict(dict)
 for f in glob.glob(f"{root}/pmc_sq/**/*counter_collection.csv", recursive=True):
     acc, n = collections.defaultdict(float), collections.defaultdict(int)
     for row in csv.DictReader(open(f)):
-        m = re.search(r"\bk_\w+", row["Kernel_Name"])
-        if m:
-            acc[(m.group(0), row["Counter_Name"])] += float(row["Counter_Value"])
-            n[(m.group(0), row["Counter_Name"])] += 1
+        k = kname(row["Kernel_Name"])
+        if k:
+            acc[(k, row["Counter_Name"])] += float(row["Counter_Value"])
+            n[(k, row["Counter_Name"])] += 1
     for (k, c), v in acc.items():
         sq[k][c] = round(v / n[(k, c)])
 res["sq_counters_per_launch"] = sq
