@@ -455,6 +455,14 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       HIP_TRY(dmalloc(&ctx->d_blur_tiles, bt.size()));
       HIP_TRY(hipMemcpy(ctx->d_blur_tiles, bt.data(), bt.size() * sizeof(short), hipMemcpyHostToDevice));
     }
+    {
+      std::vector<short> bs;
+      ctx->n_blur_items = build_blur_strips(g, bs);
+      const char *bk = std::getenv("ORBGPU_BLUR");
+      ctx->blur_strips = !(bk && std::string(bk) == "tiles");
+      HIP_TRY(dmalloc(&ctx->d_blur_strips, bs.size()));
+      HIP_TRY(hipMemcpy(ctx->d_blur_strips, bs.data(), bs.size() * sizeof(short), hipMemcpyHostToDevice));
+    }
     HIP_TRY(dmalloc(&ctx->d_cells, B * g.cells_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cands, B * g.cands_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cands_packed, B * g.cands_per_frame));
@@ -492,7 +500,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count, ctx->d_kp_angle,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes,
-                   ctx->d_fast_groups, ctx->d_blur_tiles};
+                   ctx->d_fast_groups, ctx->d_blur_tiles, ctx->d_blur_strips};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
   void *hptrs[] = {ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};

@@ -3,6 +3,9 @@
 //
 // Reference stages: BuildImagePyramid  src/features/orb_feature_extractor.cpp:504-528 (cv::resize :517)
 //                   blur in Extract    src/features/orb_feature_extractor.cpp:558-560 (cv::GaussianBlur)
+#include <algorithm>
+#include <vector>
+
 #include "orbgpu_internal.h"
 #include "tile_stage.hpp"
 
@@ -255,6 +258,148 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same blur without LDS: a half-wave (32 lanes) owns a STRIP of up to 30 output dwords x BS_R output rows and walks
+// down its rows.  Lane j holds the dword at column d0 - 1 + j of the current row (lanes 0 and nd + 1 are the strip's
+// halo), gets its neighbours' dwords with wave-shift DPP moves, blurs its 4 pixels horizontally (hblur_px) and keeps
+// the last four ROW PAIRS of that in registers (u16 halves, as hbuf above did in LDS); every new pair completes two
+// output rows.  The rows of the next chunk are in flight while a chunk is processed.  No barrier, no LDS traffic.
+// REFLECT_101: rows by index arithmetic (only in chunks that touch the top / bottom), columns by a per-lane byte
+// selector over (left neighbour's raw dword, own raw dword) -- the edge lanes load the dword that completes the pair.
+// Both strips of a wave belong to one level, so the level's geometry and row offsets are scalar.
+constexpr int BS_CH = ORBGPU_BLUR_STRIP_CHUNKS;  // chunks of 8 staged rows
+constexpr int BS_R = 8 * BS_CH - 6;              // output rows per strip
+
+__device__ __forceinline__ unsigned from_left(unsigned v) {   // lane i <- lane i - 1 (wave_shr:1)
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned from_right(unsigned v) {  // lane i <- lane i + 1 (wave_shl:1)
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+__global__ __launch_bounds__(256) void k_blur_strips(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g,
+                                                     int n_frames, Level0Src lvl0, const short4 *__restrict__ strips,
+                                                     int items_per_frame) {
+  int item, frame;
+  if (!xcd_item_frame(items_per_frame, n_frames, item, frame)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const short4 st = strips[(item * 4 + wave) * 2 + (lane >> 5)];  // (level, first output dword, first output row, dwords)
+  const int l = __builtin_amdgcn_readfirstlane((int)st.x);
+  const int w = g.lv[l].w, h = g.lv[l].h, pitch = g.lv[l].pitch;
+  const uint8_t *src = level_src(pyr, g, lvl0, frame, l, g.lv[l].off);
+  uint8_t *dst = blur + (size_t)frame * g.frame_bytes + g.lv[l].off;
+  const int j = lane & 31, nd = st.w, y0 = st.z;
+  const int d = st.y - 1 + j, gx = 4 * d;
+  // which dword the lane loads and how its row dword is put together from (left neighbour's raw dword, own raw dword)
+  int ld_off;
+  unsigned sel;
+  if (gx >= 0 && gx + 3 < w) {
+    ld_off = gx;
+    sel = 0x03020100u;
+  } else if (gx < 0) {  // columns -4..-1 <- 4 3 2 1 (column -4 is never used)
+    ld_off = 0;
+    sel = 0x01020300u;
+  } else {  // columns >= w <- 2(w-1) - column; all sources lie in [w-4, w-1], i.e. in the dwords at a and a + 4
+    const int a = (w - 4) & ~3;
+    const bool partial = (w & 3) && gx == a + 4;  // the lane of the last, partly filled dword: own = a + 4, left = a
+    ld_off = partial ? a + 4 : a;                 // the others: own = a, left = a + 4 (or unused)
+    sel = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      int col = gx + b;
+      if (col >= w) col = 2 * (w - 1) - col;
+      col = max(col, a) - a;  // 0..7; columns beyond the 3-px apron: unused, keep the selector in range
+      const int idx = partial ? (col < 4 ? col + 4 : col - 4) : col;
+      sel |= (unsigned)idx << (8 * b);
+    }
+  }
+  unsigned keep = 0;  // bytes of this lane's dword that are image pixels
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+    if (gx + p < w) keep |= 0xffu << (8 * p);
+  const bool writes = j >= 1 && j <= nd;
+  const u16x2 we0 = {18, 34}, we1 = {48, 56}, we2 = {48, 34}, we3 = {18, 0};   // even output row of a pair window
+  const u16x2 wo0 = {0, 18}, wo1 = {34, 48}, wo2 = {56, 48}, wo3 = {34, 18};   // odd
+  const uint8_t *lsrc = src + ld_off;
+  uint8_t *ldst = dst + gx;
+
+  // byte offset of staged row r (image row y0 - 3 + r, reflected)
+  auto row_off = [&](int r) -> unsigned {
+    int gy = min(y0 - 3 + r, h + 2);
+    gy = max(gy, -gy);
+    gy = min(gy, 2 * (h - 1) - gy);
+    return (unsigned)gy * (unsigned)pitch;
+  };
+  unsigned buf[2][8];  // the chunk being processed and the one in flight (the chunk loop is unrolled: no copies)
+#pragma unroll
+  for (int k = 0; k < 8; k++) buf[0][k] = *reinterpret_cast<const unsigned *>(lsrc + row_off(k));
+  unsigned P[4][4];  // the last four row pairs, horizontally blurred: pixel p of (row 2m, row 2m + 1) in u16 halves
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int p = 0; p < 4; p++) P[a][p] = 0;
+#pragma unroll
+  for (int c = 0; c < BS_CH; c++) {
+    unsigned(&cur)[8] = buf[c & 1], (&nxt)[8] = buf[(c + 1) & 1];
+    if (c + 1 < BS_CH) {
+      // wave-uniform: does any lane's chunk touch the rows that are reflected?
+      const int yb = y0 - 3 + 8 * (c + 1);
+      const bool inside = __builtin_amdgcn_readfirstlane(__all(yb >= 0 && yb + 7 < h));
+      if (inside) {
+        const uint8_t *rp = lsrc + (unsigned)yb * (unsigned)pitch;
+#pragma unroll
+        for (int k = 0; k < 8; k++) nxt[k] = *reinterpret_cast<const unsigned *>(rp + k * pitch);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) nxt[k] = *reinterpret_cast<const unsigned *>(lsrc + row_off(8 * (c + 1) + k));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      unsigned hp[2][4];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const unsigned raw = cur[2 * k + q];
+        const unsigned v = __builtin_amdgcn_perm(from_left(raw), raw, sel);
+        const unsigned win[3] = {from_left(v), v, from_right(v)};
+        hp[q][0] = hblur_px<0>(win);
+        hp[q][1] = hblur_px<1>(win);
+        hp[q][2] = hblur_px<2>(win);
+        hp[q][3] = hblur_px<3>(win);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; p++) P[k][p] = hp[0][p] | (hp[1][p] << 16);
+      // pair m = 4c + k completes output rows 2m - 6 (even) and 2m - 5 (odd): pairs m - 3 .. m
+      const int m = 4 * c + k;
+      if (m >= 3) {
+        const unsigned(&A)[4] = P[(k + 1) & 3], (&B)[4] = P[(k + 2) & 3], (&C)[4] = P[(k + 3) & 3], (&D)[4] = P[k];
+        unsigned ev[4], od[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          ev[p] = __builtin_amdgcn_udot2(as_u16x2(A[p]), we0, 32768u, false);
+          ev[p] = __builtin_amdgcn_udot2(as_u16x2(B[p]), we1, ev[p], false);
+          ev[p] = __builtin_amdgcn_udot2(as_u16x2(C[p]), we2, ev[p], false);
+          ev[p] = __builtin_amdgcn_udot2(as_u16x2(D[p]), we3, ev[p], false);
+          od[p] = __builtin_amdgcn_udot2(as_u16x2(A[p]), wo0, 32768u, false);
+          od[p] = __builtin_amdgcn_udot2(as_u16x2(B[p]), wo1, od[p], false);
+          od[p] = __builtin_amdgcn_udot2(as_u16x2(C[p]), wo2, od[p], false);
+          od[p] = __builtin_amdgcn_udot2(as_u16x2(D[p]), wo3, od[p], false);
+        }
+        // every accumulator is < 2^24: the result pixel is its byte 2
+        const unsigned oe = (__builtin_amdgcn_perm(ev[1], ev[0], 0x0c0c0602u) |
+                             (__builtin_amdgcn_perm(ev[3], ev[2], 0x0c0c0602u) << 16)) & keep;
+        const unsigned oo = (__builtin_amdgcn_perm(od[1], od[0], 0x0c0c0602u) |
+                             (__builtin_amdgcn_perm(od[3], od[2], 0x0c0c0602u) << 16)) & keep;
+        const int y = y0 + 2 * m - 6;
+        if (writes && y < h) *reinterpret_cast<unsigned *>(ldst + (unsigned)y * (unsigned)pitch) = oe;
+        if (writes && y + 1 < h) *reinterpret_cast<unsigned *>(ldst + (unsigned)(y + 1) * (unsigned)pitch) = oo;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t frame_stride, int stride, int n_frames) {
@@ -274,8 +419,36 @@ void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level) {
 }
 
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs) {
-  dim3 grid(c->geom.btiles_per_frame * xcd_frames(fs.n));
   const size_t off = (size_t)fs.f0 * c->geom.frame_bytes;
+  if (c->blur_strips) {
+    dim3 grid(c->n_blur_items * xcd_frames(fs.n));
+    hipLaunchKernelGGL(k_blur_strips, grid, dim3(256), 0, fs.stream, c->d_pyr + off, c->d_blur + off, c->geom, fs.n,
+                       slice_lvl0(c, fs), reinterpret_cast<const short4 *>(c->d_blur_strips), c->n_blur_items);
+    return;
+  }
+  dim3 grid(c->geom.btiles_per_frame * xcd_frames(fs.n));
   hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, fs.stream, c->d_pyr + off, c->d_blur + off, c->geom, fs.n, slice_lvl0(c, fs),
                      reinterpret_cast<const short4 *>(c->d_blur_tiles));
+}
+
+// strips of one frame for k_blur_strips: (level, first output dword, first output row, output dwords <= 30), two per
+// wave and both of one level (levels padded to an even count, the table to whole workgroups of 8, with empty strips)
+int build_blur_strips(const DeviceGeom &g, std::vector<short> &table) {
+  table.clear();
+  const int R = 8 * ORBGPU_BLUR_STRIP_CHUNKS - 6;
+  auto push = [&](int l, int d0, int y0, int nd) {
+    table.push_back((short)l);
+    table.push_back((short)d0);
+    table.push_back((short)y0);
+    table.push_back((short)nd);
+  };
+  for (int l = 0; l < g.levels; l++) {
+    const int wd = (g.lv[l].w + 3) / 4, nsx = (wd + 29) / 30, per = (wd + nsx - 1) / nsx;
+    int n = 0;
+    for (int y0 = 0; y0 < g.lv[l].h; y0 += R)
+      for (int d0 = 0; d0 < wd; d0 += per, n++) push(l, d0, y0, std::min(per, wd - d0));
+    if (n & 1) push(l, 0, 0, 0);
+  }
+  while ((table.size() / 4) % 8) push(g.levels - 1, 0, 0, 0);
+  return (int)(table.size() / 32);
 }

@@ -22,6 +22,7 @@
 // rows per blur tile: fewer apron rows per output row than 32, still 8 workgroups per CU (measured per 256-frame
 // batch: 32 rows 0.286 ms, 40: 0.275, 48: 0.277, 56: 0.293, 64: 0.319)
 constexpr int ORBGPU_BLUR_TILE_H = 40;
+constexpr int ORBGPU_BLUR_STRIP_CHUNKS = 7;  // k_blur_strips: 8 * 7 - 6 = 50 output rows per strip
 
 struct LevelGeom {
   int w, h, pitch;
@@ -117,6 +118,9 @@ struct orbgpu_ctx {
   int n_fast_groups = 0;
   int n_fast_groups_l0 = 0;       // groups of level 0 (the table is level-major)
   bool early_l0 = true;           // level 0's FAST groups on the second stream beside the resize chain (ORBGPU_EARLY_L0=0: off)
+  short *d_blur_strips = nullptr; // (level, first dword, first row, dwords) per strip of one frame (k_blur_strips)
+  int n_blur_items = 0;           // workgroups (8 strips) per frame
+  bool blur_strips = true;        // ORBGPU_BLUR=tiles: the LDS-tiled kernel
   short *d_blur_tiles = nullptr;  // (level, x0, y0, 0) per blur tile of one frame
   int fast_lds_rows = 0;          // tallest cell of any level: sizes the dynamic LDS of k_fast_cells
   int n_slices = 1;               // slices a batch is cut into (ORBGPU_SLICES overrides)
@@ -190,6 +194,7 @@ void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level);
 int build_fast_groups(const DeviceGeom &g, std::vector<short> &table);
 void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, int part = -1);
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs);
+int build_blur_strips(const DeviceGeom &g, std::vector<short> &table);
 void launch_orient(const orbgpu_ctx *c, FrameSlice fs);
 void launch_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                      int *d_n_out);
