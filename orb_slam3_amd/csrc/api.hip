@@ -64,7 +64,7 @@ int build_geometry(orbgpu_ctx *ctx) {
   int budget[ORBGPU_MAX_LEVELS];
   level_budget(p.scale_factor, p.levels, p.max_features, budget);
   unsigned off = 0;
-  int cell_off = 0, cand_off = 0, kp_off = 0, btile_off = 0, xt = 0, yt = 0;
+  int cell_off = 0, cand_off = 0, kp_off = 0, xt = 0, yt = 0;
   for (int l = 0; l < p.levels; l++) {
     LevelGeom &L = g.lv[l];
     const float s = (float)ctx->inv_scale[l];  // :506-508
@@ -93,8 +93,6 @@ int build_geometry(orbgpu_ctx *ctx) {
     L.kp_off = kp_off;
     L.kp_cap = std::max(budget[l], 0) + 4 * ctx->nini[l] + 4;  // the node list overshoots the budget by < 3
     kp_off += L.kp_cap;
-    L.btile_off = btile_off;
-    btile_off += ((L.w + 127) / 128) * ((L.h + ORBGPU_BLUR_TILE_H - 1) / ORBGPU_BLUR_TILE_H);
     L.xtab_off = xt;
     L.ytab_off = yt;
     xt += L.w;
@@ -106,7 +104,6 @@ int build_geometry(orbgpu_ctx *ctx) {
   g.cells_per_frame = cell_off;
   g.cands_per_frame = cand_off;
   g.kps_per_frame = kp_off;
-  g.btiles_per_frame = btile_off;
   for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) {
     g.kp_offs[l] = l < g.levels ? g.lv[l].kp_off : INT_MAX;
     g.cell_offs[l] = l < g.levels ? g.lv[l].cell_off : INT_MAX;
@@ -226,7 +223,7 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   for (int s = 0; s < n_slices; s++) {
     const int f0 = (int)((long long)n_frames * s / n_slices), f1 = (int)((long long)n_frames * (s + 1) / n_slices);
     const FrameSlice fs{f0, f1 - f0, s == 0 ? ctx->stream : ctx->slice_stream[s]};
-    const FrameSlice fb{f0, f1 - f0, ctx->slice_blur[s]};
+    const FrameSlice fb{f0, f1 - f0, ctx->no_overlap ? fs.stream : ctx->slice_blur[s]};
     hipEvent_t *sev = ctx->slice_ev[s];
     const bool timed = s == 0 && ctx->stage_timing;  // the stage timers follow slice 0
     const bool timed_fast = s == 0;                  // the FAST kernel (the roofline kernel) is always bracketed
@@ -435,31 +432,16 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       ctx->n_fast_groups_l0 = 0;
       for (size_t q = 0; q < groups.size(); q += 4)
         if (groups[q] == 0) ctx->n_fast_groups_l0++;
+      const char *nov = std::getenv("ORBGPU_NO_OVERLAP");
+      ctx->no_overlap = nov && nov[0] == '1';
       const char *el0 = std::getenv("ORBGPU_EARLY_L0");
       ctx->early_l0 = g.levels >= 2 && !(el0 && el0[0] == '0');
       HIP_TRY(dmalloc(&ctx->d_fast_groups, groups.size()));
       HIP_TRY(hipMemcpy(ctx->d_fast_groups, groups.data(), groups.size() * sizeof(short), hipMemcpyHostToDevice));
     }
     {
-      // blur tiles of one frame: (level, first column, first row, 0), so that the kernel finds its tile with one load
-      std::vector<short> bt;
-      for (int l = 0; l < g.levels; l++) {
-        const int tx = (g.lv[l].w + 127) / 128, ty = (g.lv[l].h + ORBGPU_BLUR_TILE_H - 1) / ORBGPU_BLUR_TILE_H;
-        for (int t = 0; t < tx * ty; t++) {
-          bt.push_back((short)l);
-          bt.push_back((short)((t % tx) * 128));
-          bt.push_back((short)((t / tx) * ORBGPU_BLUR_TILE_H));
-          bt.push_back(0);
-        }
-      }
-      HIP_TRY(dmalloc(&ctx->d_blur_tiles, bt.size()));
-      HIP_TRY(hipMemcpy(ctx->d_blur_tiles, bt.data(), bt.size() * sizeof(short), hipMemcpyHostToDevice));
-    }
-    {
       std::vector<short> bs;
       ctx->n_blur_items = build_blur_strips(g, bs);
-      const char *bk = std::getenv("ORBGPU_BLUR");
-      ctx->blur_strips = !(bk && std::string(bk) == "tiles");
       HIP_TRY(dmalloc(&ctx->d_blur_strips, bs.size()));
       HIP_TRY(hipMemcpy(ctx->d_blur_strips, bs.data(), bs.size() * sizeof(short), hipMemcpyHostToDevice));
     }
@@ -500,7 +482,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count, ctx->d_kp_angle,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes,
-                   ctx->d_fast_groups, ctx->d_blur_tiles, ctx->d_blur_strips};
+                   ctx->d_fast_groups, ctx->d_blur_strips};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
   void *hptrs[] = {ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};

@@ -11,15 +11,7 @@
 
 namespace {
 
-constexpr int TILE_W = 128;  // output pixels per tile row (32 lanes x 4 px: one LDS row per half-wave)
-constexpr int TILE_DW = STAGE_DW;  // dwords per staged row: 4-px apron left and right
-
-__device__ __forceinline__ int reflect101(int i, int n) {
-  // BORDER_REFLECT_101: -i -> i, (n-1)+i -> (n-1)-i ; the aprons used here are < n
-  if (i < 0) i = -i;
-  if (i >= n) i = 2 * (n - 1) - i;
-  return i;
-}
+constexpr int TILE_W = 128;  // output pixels per resize tile row (32 lanes x 4 px)
 
 // ------------------------------------------------------------------------------------------------
 // import: user images (arbitrary row stride) -> level 0 of each frame slab
@@ -152,15 +144,10 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 // Gaussian blur 7x7, sigma 2, BORDER_REFLECT_101 -- OpenCV's 8.8 fixed-point path:
 //   h = sum k_i * src[x+i-3]            (u16, <= 65280)
 //   dst = (sum k_j * h[y+j-3] + 32768) >> 16
-// One launch covers all levels of all frames.  Tile 128 x 40, apron 3 rows / 4 columns, both passes in LDS and in
-// packed integer math (the integer VALU, not HBM, is what bounds this kernel):
-//   horizontal: per pixel two byte-aligned dwords of the row (v_alignbyte_b32) and two v_dot4_u32_u8 against the
-//               kernel bytes; two rows per lane are interleaved so that LDS holds (row 2m, row 2m+1) pairs per pixel;
+// One launch covers all levels of all frames, in packed integer math:
+//   horizontal: per pixel the 12-byte window of its dword and two or three v_dot4_u32_u8 against the kernel bytes shifted
+//               to where the pixel's taps fall; two rows are interleaved into (row 2m, row 2m+1) u16 pairs per pixel;
 //   vertical:   four v_dot2_u32_u16 per pixel on those row pairs (weights chosen by the parity of the output row).
-constexpr int BT_H = ORBGPU_BLUR_TILE_H;
-constexpr int BT_ROWS = BT_H + 6;        // 46 staged rows = 23 row pairs
-constexpr int BT_PAIRS = BT_ROWS / 2;
-
 typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
 __device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
@@ -183,93 +170,16 @@ __device__ __forceinline__ unsigned hblur_px(const unsigned (&w)[3]) {
   return acc;
 }
 
-__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g,
-                                              int n_frames, Level0Src lvl0, const short4 *__restrict__ tiles) {
-  __shared__ unsigned tile[BT_ROWS * TILE_DW];
-  __shared__ __attribute__((aligned(16))) unsigned hbuf[BT_PAIRS * TILE_W];  // (h[2m][x], h[2m+1][x]) per dword
-  // tile -> (level, tile x, tile y)
-  int t, frame;
-  if (!xcd_item_frame(g.btiles_per_frame, n_frames, t, frame)) return;
-  const short4 bt = tiles[t];
-  const int l = bt.x, x0 = bt.y, y0 = bt.z;
-  const LevelGeom L = g.lv[l];
-  const size_t base = (size_t)frame * g.frame_bytes + L.off;
-  const uint8_t *src = level_src(pyr, g, lvl0, frame, l, L.off);
-
-  stage_tile<BT_ROWS>(tile, src, L.w, L.h, L.pitch, x0, y0);
-  __syncthreads();
-
-  // horizontal pass: task = (row pair, 4-pixel group)
-  for (int i = threadIdx.x; i < BT_PAIRS * (TILE_W / 4); i += 256) {
-    const int rp = i >> 5, c = i & 31;
-    unsigned w0[3], w1[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      w0[q] = tile[(2 * rp) * TILE_DW + c + q];
-      w1[q] = tile[(2 * rp + 1) * TILE_DW + c + q];
-    }
-    // window bytes 0..11 = columns 4c-4 .. 4c+7 (relative to x0); pixel p has its centre at byte 4+p, first tap 1+p
-    uint4 o;  // per pixel (row 2rp, row 2rp+1) as u16 halves
-    o.x = hblur_px<0>(w0) | (hblur_px<0>(w1) << 16);
-    o.y = hblur_px<1>(w0) | (hblur_px<1>(w1) << 16);
-    o.z = hblur_px<2>(w0) | (hblur_px<2>(w1) << 16);
-    o.w = hblur_px<3>(w0) | (hblur_px<3>(w1) << 16);
-    *reinterpret_cast<uint4 *>(&hbuf[rp * TILE_W + 4 * c]) = o;
-  }
-  __syncthreads();
-
-  // vertical pass: staged rows ry .. ry+6 of output row ry.  Even ry: pairs (ry,ry+1)(ry+2,ry+3)(ry+4,ry+5)(ry+6,-);
-  // odd ry: (-,ry)(ry+1,ry+2)(ry+3,ry+4)(ry+5,ry+6).  dot2 = a.lo*b.lo + a.hi*b.hi + c with a.lo = even staged row.
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const bool odd = ty & 1;
-  const u16x2 wt0 = odd ? u16x2{0, 18} : u16x2{18, 34};
-  const u16x2 wt1 = odd ? u16x2{34, 48} : u16x2{48, 56};
-  const u16x2 wt2 = odd ? u16x2{56, 48} : u16x2{48, 34};
-  const u16x2 wt3 = odd ? u16x2{34, 18} : u16x2{18, 0};
-  unsigned keep = 0;  // bytes of this lane's dword that are image pixels
-#pragma unroll
-  for (int p = 0; p < 4; p++)
-    if (x0 + 4 * tx + p < L.w) keep |= 0xffu << (8 * p);
-#pragma unroll
-  for (int part = 0; part < BT_H / 8; part++) {
-    const int ry = ty + 8 * part;
-    const int y = y0 + ry, x = x0 + 4 * tx;
-    if (y >= L.h || x >= L.pitch) continue;
-    const int rp0 = ry >> 1;
-    const uint4 p0 = *reinterpret_cast<const uint4 *>(&hbuf[(rp0 + 0) * TILE_W + 4 * tx]);
-    const uint4 p1 = *reinterpret_cast<const uint4 *>(&hbuf[(rp0 + 1) * TILE_W + 4 * tx]);
-    const uint4 p2 = *reinterpret_cast<const uint4 *>(&hbuf[(rp0 + 2) * TILE_W + 4 * tx]);
-    const uint4 p3 = *reinterpret_cast<const uint4 *>(&hbuf[(rp0 + 3) * TILE_W + 4 * tx]);
-    const unsigned q0[4] = {p0.x, p0.y, p0.z, p0.w}, q1[4] = {p1.x, p1.y, p1.z, p1.w};
-    const unsigned q2[4] = {p2.x, p2.y, p2.z, p2.w}, q3[4] = {p3.x, p3.y, p3.z, p3.w};
-    unsigned acc[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      acc[p] = __builtin_amdgcn_udot2(as_u16x2(q0[p]), wt0, 32768u, false);
-      acc[p] = __builtin_amdgcn_udot2(as_u16x2(q1[p]), wt1, acc[p], false);
-      acc[p] = __builtin_amdgcn_udot2(as_u16x2(q2[p]), wt2, acc[p], false);
-      acc[p] = __builtin_amdgcn_udot2(as_u16x2(q3[p]), wt3, acc[p], false);
-    }
-    // acc < 2^24: the result pixel is byte 2 of each accumulator
-    const unsigned lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
-    const unsigned hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0602u);
-    const unsigned out = (lo | (hi << 16)) & keep;
-    *reinterpret_cast<unsigned *>(blur + base + (size_t)y * L.pitch + x) = out;
-  }
-}
-
-
 // ------------------------------------------------------------------------------------------------
-// The same blur without LDS: a half-wave (32 lanes) owns a STRIP of up to 30 output dwords x BS_R output rows and walks
+// No LDS: a half-wave (32 lanes) owns a STRIP of up to 30 output dwords x 8 * BS_CH - 6 output rows and walks
 // down its rows.  Lane j holds the dword at column d0 - 1 + j of the current row (lanes 0 and nd + 1 are the strip's
 // halo), gets its neighbours' dwords with wave-shift DPP moves, blurs its 4 pixels horizontally (hblur_px) and keeps
-// the last four ROW PAIRS of that in registers (u16 halves, as hbuf above did in LDS); every new pair completes two
+// the last four ROW PAIRS of that in registers (u16 halves); every new pair completes two
 // output rows.  The rows of the next chunk are in flight while a chunk is processed.  No barrier, no LDS traffic.
 // REFLECT_101: rows by index arithmetic (only in chunks that touch the top / bottom), columns by a per-lane byte
 // selector over (left neighbour's raw dword, own raw dword) -- the edge lanes load the dword that completes the pair.
 // Both strips of a wave belong to one level, so the level's geometry and row offsets are scalar.
 constexpr int BS_CH = ORBGPU_BLUR_STRIP_CHUNKS;  // chunks of 8 staged rows
-constexpr int BS_R = 8 * BS_CH - 6;              // output rows per strip
 
 __device__ __forceinline__ unsigned from_left(unsigned v) {   // lane i <- lane i - 1 (wave_shr:1)
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
@@ -278,7 +188,7 @@ __device__ __forceinline__ unsigned from_right(unsigned v) {  // lane i <- lane 
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
 }
 
-__global__ __launch_bounds__(256) void k_blur_strips(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g,
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g,
                                                      int n_frames, Level0Src lvl0, const short4 *__restrict__ strips,
                                                      int items_per_frame) {
   int item, frame;
@@ -420,18 +330,12 @@ void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level) {
 
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs) {
   const size_t off = (size_t)fs.f0 * c->geom.frame_bytes;
-  if (c->blur_strips) {
-    dim3 grid(c->n_blur_items * xcd_frames(fs.n));
-    hipLaunchKernelGGL(k_blur_strips, grid, dim3(256), 0, fs.stream, c->d_pyr + off, c->d_blur + off, c->geom, fs.n,
-                       slice_lvl0(c, fs), reinterpret_cast<const short4 *>(c->d_blur_strips), c->n_blur_items);
-    return;
-  }
-  dim3 grid(c->geom.btiles_per_frame * xcd_frames(fs.n));
+  dim3 grid(c->n_blur_items * xcd_frames(fs.n));
   hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, fs.stream, c->d_pyr + off, c->d_blur + off, c->geom, fs.n, slice_lvl0(c, fs),
-                     reinterpret_cast<const short4 *>(c->d_blur_tiles));
+                     reinterpret_cast<const short4 *>(c->d_blur_strips), c->n_blur_items);
 }
 
-// strips of one frame for k_blur_strips: (level, first output dword, first output row, output dwords <= 30), two per
+// strips of one frame for k_blur: (level, first output dword, first output row, output dwords <= 30), two per
 // wave and both of one level (levels padded to an even count, the table to whole workgroups of 8, with empty strips)
 int build_blur_strips(const DeviceGeom &g, std::vector<short> &table) {
   table.clear();

@@ -21,8 +21,7 @@
 // this layout: level l starts `off` bytes into the frame slab, rows are `pitch` bytes apart.
 // rows per blur tile: fewer apron rows per output row than 32, still 8 workgroups per CU (measured per 256-frame
 // batch: 32 rows 0.286 ms, 40: 0.275, 48: 0.277, 56: 0.293, 64: 0.319)
-constexpr int ORBGPU_BLUR_TILE_H = 40;
-constexpr int ORBGPU_BLUR_STRIP_CHUNKS = 7;  // k_blur_strips: 8 * 7 - 6 = 50 output rows per strip
+constexpr int ORBGPU_BLUR_STRIP_CHUNKS = 7;  // k_blur: 8 * 7 - 6 = 50 output rows per strip
 
 struct LevelGeom {
   int w, h, pitch;
@@ -31,7 +30,6 @@ struct LevelGeom {
   int cell_off;                    // first cell of this level in a frame's cell table
   int cand_off, cand_cap;          // candidate sub-pool (u32 entries) inside a frame's candidate slab
   int kp_off, kp_cap;              // keypoint slots of this level inside a frame's keypoint slab
-  int btile_off;                   // first tile of this level in the blur kernel's tile index (128 x ORBGPU_BLUR_TILE_H)
   int xtab_off, ytab_off;          // resize coefficient tables (entries)
   int kp_size;                     // int(31 * scale_factors_[l])
   float scale_f;                   // (float)scale_factors_[l]
@@ -44,7 +42,6 @@ struct DeviceGeom {
   int cells_per_frame;
   int cands_per_frame;
   int kps_per_frame;      // sum of kp_cap
-  int btiles_per_frame;
   // compact copies of the per-level offsets (INT_MAX beyond the last level): one wide scalar load finds a level
   int kp_offs[ORBGPU_MAX_LEVELS], cell_offs[ORBGPU_MAX_LEVELS];
   LevelGeom lv[ORBGPU_MAX_LEVELS];
@@ -117,11 +114,10 @@ struct orbgpu_ctx {
   short *d_fast_groups = nullptr; // FastGroup table of k_fast_cells (level, cell row, first cell, cells), one frame's worth
   int n_fast_groups = 0;
   int n_fast_groups_l0 = 0;       // groups of level 0 (the table is level-major)
+  bool no_overlap = false;        // ORBGPU_NO_OVERLAP=1 (tuning aid): every kernel on the main stream, for stage times of kernels running alone
   bool early_l0 = true;           // level 0's FAST groups on the second stream beside the resize chain (ORBGPU_EARLY_L0=0: off)
-  short *d_blur_strips = nullptr; // (level, first dword, first row, dwords) per strip of one frame (k_blur_strips)
-  int n_blur_items = 0;           // workgroups (8 strips) per frame
-  bool blur_strips = true;        // ORBGPU_BLUR=tiles: the LDS-tiled kernel
-  short *d_blur_tiles = nullptr;  // (level, x0, y0, 0) per blur tile of one frame
+  short *d_blur_strips = nullptr; // (level, first dword, first row, dwords) per strip of one frame (k_blur)
+  int n_blur_items = 0;           // workgroups (8 strips) per frame  // (level, x0, y0, 0) per blur tile of one frame
   int fast_lds_rows = 0;          // tallest cell of any level: sizes the dynamic LDS of k_fast_cells
   int n_slices = 1;               // slices a batch is cut into (ORBGPU_SLICES overrides)
   XTab *d_xtab = nullptr;
