@@ -423,6 +423,19 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(hipMemcpyAsync(ctx->d_xtab, xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_ytab, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice, ctx->stream));
     {
+      std::vector<short> rs;
+      const char *rk = std::getenv("ORBGPU_RESIZE");  // ORBGPU_RESIZE=tiles: the LDS-tiled kernel for every level
+      const bool tiles = rk && std::string(rk) == "tiles";
+      const char *rt = std::getenv("ORBGPU_RESIZE_STRIPS");  // tuning aid: strips per frame a level should reach
+      const int rs_target = rt ? std::atoi(rt) : 32;
+      for (int l = 1; l < g.levels; l++) {
+        ctx->rs_strip_off[l] = (int)(rs.size() / 4);
+        ctx->rs_items[l] = tiles ? 0 : build_resize_strips(g, l, xt.data() + g.lv[l].xtab_off, rs, rs_target);
+      }
+      HIP_TRY(dmalloc(&ctx->d_rs_strips, rs.size()));
+      if (!rs.empty()) HIP_TRY(hipMemcpy(ctx->d_rs_strips, rs.data(), rs.size() * sizeof(short), hipMemcpyHostToDevice));
+    }
+    {
       std::vector<short> groups;
       ctx->n_fast_groups = build_fast_groups(g, groups);
       for (int l = 0; l < g.levels; l++) ctx->fast_lds_rows = std::max(ctx->fast_lds_rows, g.lv[l].hcell);
@@ -482,7 +495,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count, ctx->d_kp_angle,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes,
-                   ctx->d_fast_groups, ctx->d_blur_strips};
+                   ctx->d_fast_groups, ctx->d_blur_strips, ctx->d_rs_strips};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
   void *hptrs[] = {ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};

@@ -141,6 +141,121 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same resize without LDS, for levels whose column tables allow it (every scale factor up to about 2.3): a wave
+// owns a STRIP of up to 64 output dwords x 8..32 output rows and walks down the SOURCE rows its output rows need.
+// Per source row: lane i loads the strip's source dword i (one coalesced load, 8 rows ahead), every lane fetches the
+// three dwords its 4 output pixels touch with ds_bpermute (the LDS crossbar, no LDS memory), aligns them to an 8-byte
+// window (v_alignbyte_b32) and forms, per pixel, (s[sx0], s[sx0+1]) with one v_perm_b32 and the horizontal blend with
+// one v_dot2_u32_u16 against (a0, a1) << 4.  The blend of the previous source row stays in registers, so an output
+// row costs one vertical pass: (b0 * (h0 >> 4)) >> 16 is v_mul_hi_u32_u24 of (b0 << 8) and ((h << 4) & ~255).
+// Row control (which output rows a source row completes) is scalar: the wave's lanes share their rows.
+__device__ __forceinline__ unsigned mulhi24u(unsigned a, unsigned b) {
+  unsigned d;
+  asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+__global__ __launch_bounds__(256) void k_resize_strips(uint8_t *__restrict__ pyr, DeviceGeom g, int level,
+                                                       const XTab *__restrict__ xtab, const YTab *__restrict__ ytab,
+                                                       const short4 *__restrict__ strips, int items_per_frame, int n_frames,
+                                                       Level0Src lvl0) {
+  typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
+  int item, f;
+  if (!xcd_item_frame(items_per_frame, n_frames, item, f)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const short4 st = strips[item * 4 + wave];  // (first output dword, first output row, output dwords, output rows)
+  const int d0 = __builtin_amdgcn_readfirstlane((int)st.x), y0 = __builtin_amdgcn_readfirstlane((int)st.y);
+  const int nd = __builtin_amdgcn_readfirstlane((int)st.z);
+  if (nd == 0) return;  // padding of the strip table
+  const LevelGeom &S = g.lv[level - 1], &D = g.lv[level];
+  const uint8_t *src = level_src(pyr, g, lvl0, f, level - 1, S.off);
+  uint8_t *dst = pyr + (size_t)f * g.frame_bytes + D.off;
+  const XTab *xt = xtab + D.xtab_off;
+  const YTab *yt = ytab + D.ytab_off;
+  const int dx = 4 * (d0 + lane);
+  // columns (clamped index: columns >= w are computed but masked out of the store)
+  const int sbase = xt[min(4 * d0, D.w - 1)].sx0 >> 2;  // the strip's first source dword (scalar)
+  const XTab X0 = xt[min(dx, D.w - 1)];
+  const int k0 = (X0.sx0 >> 2) - sbase;
+  const unsigned o = (unsigned)X0.sx0 & 3u;
+  unsigned sel[4], coef[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const XTab X = xt[min(dx + p, D.w - 1)];
+    const unsigned q = (unsigned)(X.sx0 - X0.sx0) + o;  // byte of s[sx0] in the aligned 12-byte window; q - o <= 6
+    sel[p] = (q - o) | 0x0c00u | ((q - o + 1) << 16) | 0x0c000000u;
+    coef[p] = ((unsigned)X.a0 << 4) | ((unsigned)X.a1 << 20);  // (a0, a1) << 4 as u16 halves, each <= 32768
+  }
+  const int i0 = 4 * min(k0, 63), i1 = 4 * min(k0 + 1, 63), i2 = 4 * min(k0 + 2, 63);
+  const uint8_t *lsrc = src + 4 * min(sbase + lane, S.pitch / 4 - 1);
+  unsigned keep = 0;
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+    if (dx + p < D.w) keep |= 0xffu << (8 * p);
+  const bool writes = lane < nd;
+  uint8_t *ldst = dst + dx;
+
+  const int y_end = min(y0 + __builtin_amdgcn_readfirstlane((int)st.w), D.h);
+  const int sa = yt[y0].sy0, sb = yt[y_end - 1].sy1;
+  int y = y0;
+  YTab Y = yt[y];
+  unsigned H[2][4];  // horizontal blends << 4 (low byte cleared) of the last two source rows, by row parity
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int p = 0; p < 4; p++) H[a][p] = 0;
+
+  auto hrow = [&](unsigned raw, unsigned(&h)[4]) {
+    const unsigned w0 = (unsigned)__builtin_amdgcn_ds_bpermute(i0, (int)raw);
+    const unsigned w1 = (unsigned)__builtin_amdgcn_ds_bpermute(i1, (int)raw);
+    const unsigned w2 = (unsigned)__builtin_amdgcn_ds_bpermute(i2, (int)raw);
+    const unsigned a = __builtin_amdgcn_alignbyte(w1, w0, o), b = __builtin_amdgcn_alignbyte(w2, w1, o);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const unsigned pair = __builtin_amdgcn_perm(b, a, sel[p]);
+      h[p] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, coef[p]), 0u, false) & 0xffffff00u;
+    }
+  };
+  auto emit = [&](const unsigned(&h0)[4], const unsigned(&h1)[4]) {
+    const unsigned b0 = (unsigned)Y.b0 << 8, b1 = (unsigned)Y.b1 << 8;  // all coefficients are in [0, 2048]
+    unsigned v[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) v[p] = mulhi24u(b0, h0[p]) + mulhi24u(b1, h1[p]) + 2u;  // <= 1022
+    const u16x2 lo = __builtin_bit_cast(u16x2, v[0] | (v[1] << 16)) >> 2, hi = __builtin_bit_cast(u16x2, v[2] | (v[3] << 16)) >> 2;
+    const unsigned out = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x06040200u);
+    if (writes) *reinterpret_cast<unsigned *>(ldst + (size_t)y * D.pitch) = out & keep;
+  };
+  // source rows sa .. sb, 8 at a time, the next 8 in flight (rows beyond sb repeat sb: loaded, never used)
+  auto load8 = [&](unsigned(&buf)[8], int s0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) buf[k] = *reinterpret_cast<const unsigned *>(lsrc + (size_t)min(s0 + k, sb) * S.pitch);
+  };
+  auto chunk = [&](const unsigned(&cur)[8], unsigned(&nxt)[8], int s0) {
+    if (s0 + 8 <= sb) load8(nxt, s0 + 8);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int s = s0 + k;  // parity of s - sa = k & 1
+      if (s <= sb) {
+        hrow(cur[k], H[k & 1]);
+        while (y < y_end && Y.sy1 == s) {
+          if (Y.sy0 == s) emit(H[k & 1], H[k & 1]);
+          else emit(H[(k & 1) ^ 1], H[k & 1]);
+          y++;
+          Y = yt[min(y, D.h - 1)];
+        }
+      }
+    }
+  };
+  unsigned buf[2][8];
+  load8(buf[0], sa);
+  for (int s0 = sa; s0 <= sb; s0 += 16) {
+    chunk(buf[0], buf[1], s0);
+    if (s0 + 8 <= sb) chunk(buf[1], buf[0], s0 + 8);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Gaussian blur 7x7, sigma 2, BORDER_REFLECT_101 -- OpenCV's 8.8 fixed-point path:
 //   h = sum k_i * src[x+i-3]            (u16, <= 65280)
 //   dst = (sum k_j * h[y+j-3] + 32768) >> 16
@@ -322,10 +437,54 @@ void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t fr
 
 void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level) {
   const LevelGeom &D = c->geom.lv[level];
+  if (c->rs_items[level] > 0) {
+    dim3 grid(c->rs_items[level] * xcd_frames(fs.n));
+    hipLaunchKernelGGL(k_resize_strips, grid, dim3(256), 0, fs.stream, c->d_pyr + (size_t)fs.f0 * c->geom.frame_bytes, c->geom,
+                       level, c->d_xtab, c->d_ytab, reinterpret_cast<const short4 *>(c->d_rs_strips) + c->rs_strip_off[level],
+                       c->rs_items[level], fs.n, slice_lvl0(c, fs));
+    return;
+  }
   dim3 grid(((D.w + TILE_W - 1) / TILE_W) * ((D.h + RS_TILE_H - 1) / RS_TILE_H) * xcd_frames(fs.n));
   const size_t lds = (size_t)c->rs_pitch[level] * c->rs_rows[level];
   hipLaunchKernelGGL(k_resize_level, grid, dim3(256), lds, fs.stream, c->d_pyr + (size_t)fs.f0 * c->geom.frame_bytes, c->geom,
                      level, c->d_xtab, c->d_ytab, c->rs_pitch[level], fs.n, slice_lvl0(c, fs));
+}
+
+// strips of one frame's level for k_resize_strips: (first output dword, first output row, output dwords, output rows),
+// four per workgroup (padded with empty strips).  A wave walks its rows one after the other, so the small levels get
+// shorter strips: more waves, each done sooner (the last levels of a VGA pyramid are bound by that walk, not by bytes).  Returns the workgroups per frame, or 0 when the level's column table does not
+// fit the kernel (a pixel quad reaching more than 8 source bytes, or no strip width >= 8): k_resize_level then.
+int build_resize_strips(const DeviceGeom &g, int level, const XTab *xt, std::vector<short> &table, int strip_target) {
+  const LevelGeom &S = g.lv[level - 1], &D = g.lv[level];
+  const int wd = D.pitch / 4;  // the padding dwords of a row are written too (as zeros)
+  auto sx0 = [&](int x) { return xt[std::min(x, D.w - 1)].sx0; };
+  for (int d = 0; d < wd; d++)
+    if (sx0(4 * d + 3) - sx0(4 * d) > 6) return 0;
+  // a strip's source dwords (first pixel's sx0 .. last pixel's sx0 + 1) must be 64 consecutive ones at most
+  auto fits = [&](int d0, int nd) { return ((sx0(4 * (d0 + nd) - 1) + 1) >> 2) - (sx0(4 * d0) >> 2) <= 63; };
+  int per = 0;
+  for (int nsx = (wd + 63) / 64; nsx <= wd; nsx++) {
+    per = (wd + nsx - 1) / nsx;
+    bool ok = true;
+    for (int d0 = 0; d0 < wd && ok; d0 += per) ok = fits(d0, std::min(per, wd - d0));
+    if (ok) break;
+    per = 0;
+  }
+  if (per < 8 || S.pitch < 4) return 0;
+  const int nsx = (wd + per - 1) / per;
+  int rows = 32;  // output rows per strip: at least strip_target strips per frame, down to 8 rows
+  while (rows > 8 && nsx * ((D.h + rows - 1) / rows) < strip_target) rows /= 2;
+  int n = 0;
+  for (int y0 = 0; y0 < D.h; y0 += rows)
+    for (int d0 = 0; d0 < wd; d0 += per, n++) {
+      table.push_back((short)d0);
+      table.push_back((short)y0);
+      table.push_back((short)std::min(per, wd - d0));
+      table.push_back((short)rows);
+    }
+  for (; n % 4; n++)
+    for (int q = 0; q < 4; q++) table.push_back(0);
+  return n / 4;
 }
 
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs) {

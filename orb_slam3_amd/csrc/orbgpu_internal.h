@@ -120,6 +120,8 @@ struct orbgpu_ctx {
   int n_blur_items = 0;           // workgroups (8 strips) per frame  // (level, x0, y0, 0) per blur tile of one frame
   int fast_lds_rows = 0;          // tallest cell of any level: sizes the dynamic LDS of k_fast_cells
   int n_slices = 1;               // slices a batch is cut into (ORBGPU_SLICES overrides)
+  short *d_rs_strips = nullptr;   // k_resize_strips: (first dword, first row, dwords, 0) per strip, level after level
+  int rs_strip_off[ORBGPU_MAX_LEVELS]{}, rs_items[ORBGPU_MAX_LEVELS]{};  // first strip / workgroups per frame (0: k_resize_level)
   XTab *d_xtab = nullptr;
   YTab *d_ytab = nullptr;
   CellEntry *d_cells = nullptr;   // [frame][cells_per_frame]
@@ -191,6 +193,7 @@ int build_fast_groups(const DeviceGeom &g, std::vector<short> &table);
 void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, int part = -1);
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs);
 int build_blur_strips(const DeviceGeom &g, std::vector<short> &table);
+int build_resize_strips(const DeviceGeom &g, int level, const XTab *xt, std::vector<short> &table, int strip_target);
 void launch_orient(const orbgpu_ctx *c, FrameSlice fs);
 void launch_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                      int *d_n_out);

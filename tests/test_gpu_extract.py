@@ -123,6 +123,9 @@ def _scene(kind, seed, h, w):
     (1280, 960, 12000, 1.2, 2, 12, 5, "noise", 52),     # the same with 1024 threads and two levels
     (640, 480, 1960, 1.2, 1, 12, 5, "noise", 53),       # node lists just below the LDS limit (about 154 KB of dynamic LDS)
     (640, 480, 2040, 1.2, 1, 12, 5, "noise", 54),       # ... and just above it
+    (900, 700, 800, 1.9, 3, 20, 7, "rich", 55),         # steep pyramids: 1.9 still takes the strip resize kernel,
+    (900, 700, 800, 2.2, 3, 20, 7, "rich", 56),         # 2.2 and 2.35 the LDS-tiled one (a pixel quad reaches more
+    (1000, 800, 800, 2.35, 3, 20, 7, "noise", 57),      # than 8 source bytes)
 ])
 def test_extract_parameter_sweep(oracle, w, h, nfeat, scale, levels, fi, fm, kind, seed):
     """other constructor arguments, image sizes and degenerate scenes: keypoints and descriptors against the oracle"""
@@ -186,3 +189,23 @@ def test_extract_random_configurations(oracle, seed):
     assert np.array_equal(ft.keypoints["angle"], okp["angle"].astype(np.float32)), cfg
     assert np.array_equal(ft.descriptors, odesc), cfg
     fe.close()
+
+
+def test_resize_kernels_agree(oracle, monkeypatch):
+    """the LDS-tiled resize kernel (the fallback for steep scale factors) forced for an ordinary pyramid: the same
+    keypoints and descriptors as the strip kernel and the oracle"""
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    w, h, nfeat = 517, 389, 700
+    img = synth.frame(77, h, w)
+    okp, odesc = oracle.extract_literal(oracle.params(w, h, 1.2, 8, 20, 7), img, nfeat)
+    for mode in ("tiles", None):
+        if mode:
+            monkeypatch.setenv("ORBGPU_RESIZE", mode)
+        else:
+            monkeypatch.delenv("ORBGPU_RESIZE", raising=False)
+        fe = ORBFeatureExtractor(w, h, 1.2, 8, 20, 7, max_features=nfeat)
+        ft = Features(w, h)
+        assert fe.Extract(img, ft, nfeat) == 0
+        _kp_equal(ft.keypoints, okp)
+        assert np.array_equal(ft.descriptors, odesc)
+        fe.close()
