@@ -419,7 +419,8 @@ def main():
     # their instruction mix (tools/valu_rate.hip: ~0.9 for min/max/perm/dot/mad24, ~1.6 for add/and/shift).  Instruction
     # counts per launch come from the committed counter pass (they do not change from run to run), times from this run
     if sq:
-        stage_of = {"k_resize_level": ("pyramid", g.levels - 1), fast_kernel: ("fast_score", 1), "k_quadtree": ("quadtree", 1),
+        resize_kernel = "k_resize_strips" if "k_resize_strips" in sq else "k_resize_level"
+        stage_of = {resize_kernel: ("pyramid", g.levels - 1), fast_kernel: ("fast_score", 1), "k_quadtree": ("quadtree", 1),
                     "k_blur": ("blur", 1), "k_orient": ("orient", 1), "k_describe": ("describe", 1)}
         vi = {}
         for kname, (stage, launches) in stage_of.items():
