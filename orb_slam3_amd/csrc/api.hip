@@ -229,13 +229,14 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     const bool timed_fast = s == 0;                  // the FAST kernel (the roofline kernel) is always bracketed
     if (s > 0) HIP_TRY(hipStreamWaitEvent(fs.stream, ev[0], 0));  // fork: after everything already on the context's stream
     const bool early = ctx->early_l0;
-    if (early) {  // level 0 needs no pyramid: its FAST groups on the slice's second stream (idle until the blur)
+    if (early) {  // level 0 needs no pyramid: its FAST groups on a stream of their own, beside the resize chain
+      const FrameSlice fl{f0, f1 - f0, ctx->no_overlap ? fs.stream : ctx->slice_l0[s]};
       HIP_TRY(hipEventRecord(sev[3], fs.stream));  // after everything already on the stream (the caller's images included)
-      HIP_TRY(hipStreamWaitEvent(fb.stream, sev[3], 0));
-      if (timed) HIP_TRY(hipEventRecord(ev[10], fb.stream));
-      launch_fast_cells(ctx, fb, nullptr, 1);
-      if (timed) HIP_TRY(hipEventRecord(ev[11], fb.stream));
-      HIP_TRY(hipEventRecord(sev[4], fb.stream));
+      HIP_TRY(hipStreamWaitEvent(fl.stream, sev[3], 0));
+      if (timed) HIP_TRY(hipEventRecord(ev[10], fl.stream));
+      launch_fast_cells(ctx, fl, nullptr, 1);
+      if (timed) HIP_TRY(hipEventRecord(ev[11], fl.stream));
+      HIP_TRY(hipEventRecord(sev[4], fl.stream));
     }
     for (int l = 1; l < L; l++) launch_pyramid_level(ctx, fs, l);
     if (timed_fast) HIP_TRY(hipEventRecord(ev[1], fs.stream));
@@ -409,6 +410,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     ctx->stream = ctx->own_stream;
     for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
       if (k > 0) HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_stream[k], hipStreamNonBlocking));
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_l0[k], hipStreamNonBlocking));
       HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_blur[k], hipStreamNonBlocking));
       for (auto &e : ctx->slice_ev[k]) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
@@ -507,12 +509,14 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
     if (ctx->slice_stream[k]) (void)hipStreamSynchronize(ctx->slice_stream[k]);
     if (ctx->slice_blur[k]) (void)hipStreamSynchronize(ctx->slice_blur[k]);
+    if (ctx->slice_l0[k]) (void)hipStreamSynchronize(ctx->slice_l0[k]);
   }
   for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
     for (auto &e : ctx->slice_ev[k])
       if (e) (void)hipEventDestroy(e);
     if (ctx->slice_stream[k]) (void)hipStreamDestroy(ctx->slice_stream[k]);
     if (ctx->slice_blur[k]) (void)hipStreamDestroy(ctx->slice_blur[k]);
+    if (ctx->slice_l0[k]) (void)hipStreamDestroy(ctx->slice_l0[k]);
   }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

@@ -100,6 +100,7 @@ struct orbgpu_ctx {
   hipStream_t own_stream = nullptr;
   static constexpr int MAX_SLICES = 4;
   hipStream_t slice_stream[MAX_SLICES]{};  // slices 1.. of a batch (slice 0 runs on `stream`)
+  hipStream_t slice_l0[MAX_SLICES]{};      // level 0's FAST launch of a slice runs beside its resize chain
   hipStream_t slice_blur[MAX_SLICES]{};    // the blur of a slice runs beside its (latency-bound) quadtree kernel
   hipEvent_t slice_ev[MAX_SLICES][5]{};    // fork / blur-may-start / slice-done
   std::mutex mu;
