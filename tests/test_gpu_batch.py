@@ -351,3 +351,46 @@ def test_caller_stream_and_capacity_flag(oracle):
         if n[pi] > small or n[pi + 1] > small:
             assert nm2[pi] == 0 and (m2[pi] == -1).all()            # an overflowed frame counts as empty
     fe.close()
+
+
+@pytest.mark.parametrize("switch", ["ORBGPU_EARLY_L0=0", "ORBGPU_NO_OVERLAP=1", "ORBGPU_RESIZE=tiles", "slices=2"])
+def test_schedules_give_identical_results(monkeypatch, switch):
+    """the stage schedule (level 0's FAST launch beside the resize chain, blur beside quadtree and orientation, frame
+    slices) and the resize kernel are choices of speed only: each alternative writes the same bytes as the default"""
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    W, H, NF, B = 417, 311, 600, 11
+    frames = synth.sequence(91, B, H, W)
+    dev = torch.device("cuda", 0)
+    d_imgs = torch.from_numpy(frames).to(dev)
+
+    def run(env):
+        if env and "=" in env and not env.startswith("slices"):
+            k, v = env.split("=")
+            monkeypatch.setenv(k, v)
+        fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_batch=B, max_features=NF)
+        if env == "slices=2":
+            assert lib.orbgpu_set_batch_slices(fe.handle, 2) == 0
+        cap = fe.geometry(NF).keypoint_capacity
+        d_kp = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(2):  # twice: the second call follows the first one's kernels on every stream
+            rc = lib.orbgpu_extract_batch_device(fe.handle, d_imgs.data_ptr(), W * H, W, B, NF, d_kp.data_ptr(),
+                                                 d_desc.data_ptr(), cap, d_n.data_ptr())
+            assert rc == 0, lib.orbgpu_last_error(fe.handle)
+        assert lib.orbgpu_synchronize(fe.handle) == 0
+        out = d_kp.cpu().numpy(), d_desc.cpu().numpy(), d_n.cpu().numpy()
+        fe.close()
+        if env and "=" in env and not env.startswith("slices"):
+            monkeypatch.delenv(env.split("=")[0])
+        return out
+
+    ref = run(None)
+    alt = run(switch)
+    assert ref[2].min() > 50
+    for a, b in zip(ref, alt):
+        assert np.array_equal(a, b)
