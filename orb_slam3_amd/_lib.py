@@ -3,6 +3,7 @@
 There is no CPU fallback: if the HIP library is missing or no GPU is usable this module raises.
 """
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -88,10 +89,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
-        raise OrbGpuError(E_HIP, f"{LIB_PATH} is missing: build it with `make -C orb_slam3_amd/csrc` "
+    # ORBGPU_LIBRARY: another build of the same library (A/B timing of two builds on one box); default: the in-tree one
+    path = Path(os.environ.get("ORBGPU_LIBRARY") or LIB_PATH)
+    if not path.exists():
+        raise OrbGpuError(E_HIP, f"{path} is missing: build it with `make -C orb_slam3_amd/csrc` "
                                  "(there is no CPU fallback)")
-    lib = C.CDLL(str(LIB_PATH))
+    lib = C.CDLL(str(path))
     vp, i32, u32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64, C.c_double
     sig = {
         "orbgpu_create": (i32, [C.POINTER(Params), C.POINTER(vp)]),

@@ -102,7 +102,7 @@ __host__ __device__ constexpr size_t fast_cells_lds_bytes(int rows) {
   return (size_t)(rows + 6) * FC_TPB       // pixel tile
          + (size_t)(rows + 2) * FC_TPB     // score tile
          + (size_t)rows * FC_QPITCH * 2    // survivor queue (u16)
-         + (size_t)rows * FC_MAXK * 16     // row masks per (row, cell): kept (u64), kept-hi (u64)
+         + (size_t)rows * FC_MAXK * 8      // row mask per (row, cell): kept (u64); 8 workgroups per CU need <= 20 KB
          + FC_TP * 4                       // column validity mask per quad
          + 16;
 }
@@ -140,8 +140,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   unsigned *tile = fc_lds;
   unsigned *stile = tile + (lds_rows + 6) * FC_TP;
   unsigned short *queue = reinterpret_cast<unsigned short *>(stile + (lds_rows + 2) * FC_TP);
-  unsigned *rmask = reinterpret_cast<unsigned *>(queue + lds_rows * FC_QPITCH);  // [row][cell]{lo.x, lo.y, hi.x, hi.y}
-  unsigned *colmask = rmask + lds_rows * FC_MAXK * 4;
+  // [row][cell] u64: pixels kept by NMS -- at iniThFAST first; a cell that kept nothing then (its masks are still zero)
+  // is the only kind the minThFAST pass writes to, so one mask serves both passes
+  unsigned *rmask = reinterpret_cast<unsigned *>(queue + lds_rows * FC_QPITCH);
+  unsigned *colmask = rmask + lds_rows * FC_MAXK * 2;
   int *q_count = reinterpret_cast<int *>(colmask + FC_TP);
   int item, frame;
   if (!xcd_item_frame(groups_per_frame, n_frames, item, frame)) return;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     // meanwhile: clear the score tile and the row masks (16 bytes per lane and store), per-quad column masks
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < (nrow + 2) * (FC_TP / 4); i += 256) reinterpret_cast<uint4 *>(stile)[i] = z4;
-    if (tid < nrow * FC_MAXK) reinterpret_cast<uint4 *>(rmask)[tid] = z4;
+    if (tid < (nrow * FC_MAXK + 1) / 2) reinterpret_cast<uint4 *>(rmask)[tid] = z4;
     if (tid < 2) q_count[tid] = 0;  // [0] packed queue counts, [1] bit j: cell j falls back to minThFAST
     if (tid < FC_TP) {
       unsigned m = 0;
@@ -327,8 +329,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     }
   };
   // 3x3 NMS of (decoded) queue entry q inside the pixel's own cell; survivors with score >= t_keep in the cells of
-  // need_mask set their bit in the cell's row mask `which` (0: kept at minThFAST, 2: kept at iniThFAST)
-  auto nms_entry = [&](int q, int t_keep, unsigned need_mask, int which) {
+  // need_mask set their bit in the cell's row mask
+  auto nms_entry = [&](int q, int t_keep, unsigned need_mask) {
     const int e = queue[q];
     const int ey = e >> 8, cx = e & 255;
     const uint8_t *c = sb + (ey + 1) * FC_TPB + cx + 4;
@@ -343,14 +345,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     nl = xx == 0 ? 0 : nl;                  // "NMS does not see across the seam"
     nr = xx == L.wcell - 1 ? 0 : nr;        // (beyond X1 nothing was scored)
     const int nm = vmax3(c[-FC_TPB], c[FC_TPB], max(nl, nr));
-    if (v > nm) atomicOr(rmask + ((ey * FC_MAXK + j) << 2) + which + (xx >> 5), 1u << (xx & 31));
+    if (v > nm) atomicOr(rmask + ((ey * FC_MAXK + j) << 1) + (xx >> 5), 1u << (xx & 31));
   };
-  // wave = cell, lane = row: survivors of the cell's row masks `which` in raster order -> the cell's fixed slot of the
+  // wave = cell, lane = row: survivors of the cell's row masks in raster order -> the cell's fixed slot of the
   // candidate pool; returns the number written (wave-uniform)
-  auto emit_cell = [&](int j, int which) -> int {
+  auto emit_cell = [&](int j) -> int {
     const int cx0 = X0 + j * L.wcell;
     uint2 mk = make_uint2(0, 0);
-    if (lane < nrow) mk = *reinterpret_cast<const uint2 *>(rmask + ((lane * FC_MAXK + j) << 2) + which);
+    if (lane < nrow) mk = *reinterpret_cast<const uint2 *>(rmask + ((lane * FC_MAXK + j) << 1));
     const int cnt = __popc(mk.x) + __popc(mk.y);
     const int incl = wave_incl_scan(cnt);
     const int total = __builtin_amdgcn_readlane(incl, 63);
@@ -375,12 +377,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   // ---- iniThFAST: score the front of the queue, NMS, emit ---------------------------------------------------------
   for (int q = tid; q < n_hi; q += 256) score_entry(q, 0xfu);
   __syncthreads();
-  for (int q = tid; q < n_hi; q += 256) nms_entry(q, t_hi, 0xfu, 2);
+  for (int q = tid; q < n_hi; q += 256) nms_entry(q, t_hi, 0xfu);
   __syncthreads();
   if (wave < G.ncell) {
     // a cell without columns (beyond the last detection column) holds nothing at either threshold
     const bool has_cols = X0 + wave * L.wcell <= X1;
-    const int total = has_cols ? emit_cell(wave, 2) : 0;
+    const int total = has_cols ? emit_cell(wave) : 0;
     if (total == 0) {
       if (has_cols) {
         if (lane == 0) atomicOr(reinterpret_cast<unsigned *>(q_count + 1), 1u << wave);  // falls back to minThFAST
@@ -397,11 +399,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   for (int q = qcap - 1 - tid; q >= qcap - n_lo; q -= 256) score_entry(q, score_mask);
   if (fallback == 0) return;
   __syncthreads();
-  for (int q = tid; q < n_hi; q += 256) nms_entry(q, 1, fallback, 0);
-  for (int q = qcap - 1 - tid; q >= qcap - n_lo; q -= 256) nms_entry(q, 1, fallback, 0);
+  for (int q = tid; q < n_hi; q += 256) nms_entry(q, 1, fallback);
+  for (int q = qcap - 1 - tid; q >= qcap - n_lo; q -= 256) nms_entry(q, 1, fallback);
   __syncthreads();
   if (wave < G.ncell && ((fallback >> wave) & 1u)) {
-    if (emit_cell(wave, 0) == 0 && lane == 0) ce[wave] = CellEntry{(G.row * L.ncols + G.j0 + wave) * cell_slot, 0};
+    if (emit_cell(wave) == 0 && lane == 0) ce[wave] = CellEntry{(G.row * L.ncols + G.j0 + wave) * cell_slot, 0};
   }
 }
 
@@ -436,19 +438,23 @@ void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, 
   if (count <= 0) return;
   dim3 grid(count * xcd_frames(fs.n));
   const FastGroup *groups = reinterpret_cast<const FastGroup *>(c->d_fast_groups) + first;
-  const size_t lds = fast_cells_lds_bytes(c->fast_lds_rows);
+  // dynamic LDS by the tallest cell of the launch's own levels: 32 rows (level 0 of a VGA frame) fit 8 workgroups per CU,
+  // 33 rows and more only 7 -- and the kernel's time follows its occupancy
+  int rows = 0;
+  for (int l = (part == 0 ? 1 : 0); l < (part == 1 ? 1 : g.levels); l++) rows = std::max(rows, g.lv[l].hcell);
+  const size_t lds = fast_cells_lds_bytes(rows);
   const uint8_t *pyr = c->d_pyr + (size_t)fs.f0 * g.frame_bytes;
   CellEntry *cells = c->d_cells + (size_t)fs.f0 * g.cells_per_frame;
   unsigned *cands = c->d_cands + (size_t)fs.f0 * g.cands_per_frame;
   if (score_dump)
     hipLaunchKernelGGL((k_fast_cells<true, 0>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
-                       fs.n, slice_lvl0(c, fs), c->fast_lds_rows, score_dump);
+                       fs.n, slice_lvl0(c, fs), rows, score_dump);
   else if (part == 1)
     hipLaunchKernelGGL((k_fast_cells<false, 1>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
-                       fs.n, slice_lvl0(c, fs), c->fast_lds_rows, (uint8_t *)nullptr);
+                       fs.n, slice_lvl0(c, fs), rows, (uint8_t *)nullptr);
   else
     hipLaunchKernelGGL((k_fast_cells<false, 0>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
-                       fs.n, slice_lvl0(c, fs), c->fast_lds_rows, (uint8_t *)nullptr);
+                       fs.n, slice_lvl0(c, fs), rows, (uint8_t *)nullptr);
 }
 
 
