@@ -216,10 +216,30 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   const int d_r = __builtin_amdgcn_readfirstlane(div_small(256, ncg, inv_ncg)), d_c = 256 - d_r * ncg;
   const int qcap = lds_rows * FC_QPITCH;
   // ---- phase 1 + push, 8 passes (2048 quads) at a time ------------------------------------------------------
-  // Survivors of the quick test at iniThFAST go to the front of the queue, those that only pass at minThFAST to its
-  // back: a pixel scoring below iniThFAST can neither be kept nor suppress anything in a cell that keeps a corner at
-  // iniThFAST (NMS is a strict > against a value >= iniThFAST), so the back of the queue is only ever scored for cells
-  // that fall back to minThFAST.
+  // Survivors of the quick test at iniThFAST go to the front of the queue.  Those that only pass at minThFAST stay in
+  // the lane's registers (one bit per pixel, keep_lo): a pixel scoring below iniThFAST can neither be kept nor suppress
+  // anything in a cell that keeps a corner at iniThFAST (NMS is a strict > against a value >= iniThFAST), so they are
+  // only pushed (to the back of the queue) and scored when a cell of the group falls back to minThFAST.
+  unsigned keep_lo[2] = {0, 0};  // nq4 <= 33 x 64 quads: two blocks of 2048
+  // one LDS atomic per wave for a block's survivors; the order inside the queue is free.  Entries are (quad << 2 | pixel)
+  auto push_block = [&](unsigned m, int qbase, bool back) {
+    const int cnt = __popc(m);
+    const int incl = wave_incl_scan(cnt);
+    const int tot = __builtin_amdgcn_readlane(incl, 63);
+    if (tot == 0) return;
+    int basep = 0;
+    if (lane == 0) basep = atomicAdd(q_count, back ? tot << 16 : tot);
+    basep = __builtin_amdgcn_readfirstlane(basep);
+    int pos = back ? qcap - 1 - ((basep >> 16) + incl - cnt) : (basep & 0xffff) + incl - cnt;
+    const int dir = back ? -1 : 1;
+    const unsigned qt = (unsigned)(qbase + tid) << 2;
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      queue[pos] = (unsigned short)(qt + ((unsigned)(bit & 7) << 10) + ((unsigned)bit >> 3));
+      pos += dir;
+    }
+  };
   for (int qbase = 0; qbase < nq4; qbase += 2048) {
     unsigned acc_lo = 0, acc_hi = 0;  // bit 8 * p + pass: pixel p of this lane's quad in pass `pass` may be a corner
     const int npass = min(8, (nq4 - qbase + 255) >> 8);
@@ -272,35 +292,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
         ry++;
       }
     }
-    // ---- push the survivors as (quad << 2 | pixel): one LDS atomic per wave; the order inside the queue is free ----
-    {
-      acc_lo &= ~acc_hi;  // only at minThFAST
-      const int cnt = __popc(acc_hi) | (__popc(acc_lo) << 16);  // both scans at once
-      const int incl = wave_incl_scan(cnt);
-      const int tot = __builtin_amdgcn_readlane(incl, 63);
-      if (tot) {
-        int basep = 0;
-        if (lane == 0) basep = atomicAdd(q_count, tot);
-        const int at = __builtin_amdgcn_readfirstlane(basep) + incl - cnt;
-        int pos_hi = at & 0xffff, pos_lo = qcap - 1 - (at >> 16);
-        const unsigned qt = (unsigned)(qbase + tid) << 2;
-        unsigned m = acc_hi;
-        while (m) {
-          const int bit = __ffs(m) - 1;
-          m &= m - 1;
-          queue[pos_hi++] = (unsigned short)(qt + ((unsigned)(bit & 7) << 10) + ((unsigned)bit >> 3));
-        }
-        m = acc_lo;
-        while (m) {
-          const int bit = __ffs(m) - 1;
-          m &= m - 1;
-          queue[pos_lo--] = (unsigned short)(qt + ((unsigned)(bit & 7) << 10) + ((unsigned)bit >> 3));
-        }
-      }
-    }
+    if (qbase == 0) keep_lo[0] = acc_lo & ~acc_hi;  // only at minThFAST
+    else keep_lo[1] = acc_lo & ~acc_hi;
+    push_block(acc_hi, qbase, false);
   }
   __syncthreads();
-  const int n_hi = *q_count & 0xffff, n_lo = *q_count >> 16;
+  const int n_hi = *q_count & 0xffff;
   const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
   uint8_t *sb = reinterpret_cast<uint8_t *>(stile);
   const int bnd0 = X0 - xs0;  // tile column - 4 of the first pixel of cell j0
@@ -396,6 +393,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   const unsigned fallback = (unsigned)q_count[1];
   const unsigned score_mask = DUMP ? 0xfu : fallback;
   if (score_mask == 0) return;
+  push_block(keep_lo[0], 0, true);
+  if (nq4 > 2048) push_block(keep_lo[1], 2048, true);
+  __syncthreads();
+  const int n_lo = *q_count >> 16;
   for (int q = qcap - 1 - tid; q >= qcap - n_lo; q -= 256) score_entry(q, score_mask);
   if (fallback == 0) return;
   __syncthreads();
