@@ -364,15 +364,33 @@ def main():
         traffic = tj["kernels"].get(fast_kernel, {}).get("hbm_bytes")
         traffic_src = "profiles/r2_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this workload)"
         sq = tj.get("sq_counters_per_launch", {})
+    # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/):
+    # the live figure brackets the launch with two HIP events and so holds the launch's dispatch and the events' own
+    # processing (about 10 us) on top of the kernel's duration
+    rocprof_ms = None
+    sfile = ROOT / "profiles" / "r2_bench_no_large_kernel_stats.csv"
+    if sfile.exists() and headline:
+        import csv
+        want = "k_fast_cells<false, 0>" if early_l0 else "k_fast_cells<false, 0>"
+        for row in csv.DictReader(open(sfile)):
+            if want in row.get("Name", ""):
+                rocprof_ms = round(float(row["AverageNs"]) * 1e-6, 4)
     roofline = {"bound": "hbm", "kernel": fast_kernel, "achieved": round(fast_gbs, 2), "peak": hbm_peak,
                 "unit": "GB/s", "frac": round(fast_gbs / hbm_peak, 5), "traffic": traffic,
                 "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P_fast * B, "traffic_source": traffic_src,
+                "avg_launch_ms_in_committed_rocprof_stats": rocprof_ms,
+                "avg_launch_ms_source": "live: HIP events on the kernel's stream around the launch (dispatch + the events' own "
+                                        "processing included, ~10 us more than the kernel itself); rocprof figure: "
+                                        "profiles/r2_bench_no_large_kernel_stats.csv, valid for the default workload with "
+                                        "level 0's launch beside the pyramid",
                 "launch": ("pyramid levels >= 1 of every frame, alone on the device; level 0's groups are a second launch of "
                            "the same kernel (k_fast_cells<false,1>, pipeline.fast_level0) that needs no pyramid and runs "
                            "beside the resize chain") if early_l0 else "all pyramid levels of every frame",
-                "limiter": "instruction issue, not HBM: the kernel (FAST score + per-cell NMS, fallback and compaction, fused) "
-                           "issues about one vector instruction per clock per CU, the measured ceiling of its mix "
-                           "(profiles/r2_hbm_traffic.json sq_counters_per_launch, profiles/r2_valu_rate.txt)"}
+                "limiter": "not HBM: the kernel (FAST score + per-cell NMS, fallback and compaction, fused) issues about one "
+                           "vector instruction per clock per CU, the measured ceiling of its mix "
+                           "(profiles/r2_hbm_traffic.json sq_counters_per_launch, profiles/r2_valu_rate.txt), and its time "
+                           "follows its occupancy (7-8 workgroups of seven barrier-separated phases per CU) and its "
+                           "instruction count about one to one (DESIGN.md, 'Tried and set aside in round 2')"}
     # whole extraction against SURVEY 8d's per-frame figure A = 5P - px0 - px7 + 1978 N
     A = 5 * P - g.w[0] * g.h[0] - g.w[g.levels - 1] * g.h[g.levels - 1] + 1978 * NF
     ext_s = st[6] * 1e-3
