@@ -369,9 +369,9 @@ def main():
     # processing (about 10 us) on top of the kernel's duration
     rocprof_ms = None
     sfile = ROOT / "profiles" / "r2_bench_no_large_kernel_stats.csv"
-    if sfile.exists() and headline:
+    if sfile.exists() and headline and early_l0:
         import csv
-        want = "k_fast_cells<false, 0>" if early_l0 else "k_fast_cells<false, 0>"
+        want = "k_fast_cells<false, 0>"
         for row in csv.DictReader(open(sfile)):
             if want in row.get("Name", ""):
                 rocprof_ms = round(float(row["AverageNs"]) * 1e-6, 4)
