@@ -19,8 +19,6 @@
 
 // One pyramid level as the kernels see it.  All images of a frame (pyramid, score, blurred) share
 // this layout: level l starts `off` bytes into the frame slab, rows are `pitch` bytes apart.
-// rows per blur tile: fewer apron rows per output row than 32, still 8 workgroups per CU (measured per 256-frame
-// batch: 32 rows 0.286 ms, 40: 0.275, 48: 0.277, 56: 0.293, 64: 0.319)
 constexpr int ORBGPU_BLUR_STRIP_CHUNKS = 7;  // k_blur: 8 * 7 - 6 = 50 output rows per strip
 
 struct LevelGeom {
@@ -118,7 +116,7 @@ struct orbgpu_ctx {
   bool no_overlap = false;        // ORBGPU_NO_OVERLAP=1 (tuning aid): every kernel on the main stream, for stage times of kernels running alone
   bool early_l0 = true;           // level 0's FAST groups on the second stream beside the resize chain (ORBGPU_EARLY_L0=0: off)
   short *d_blur_strips = nullptr; // (level, first dword, first row, dwords) per strip of one frame (k_blur)
-  int n_blur_items = 0;           // workgroups (8 strips) per frame  // (level, x0, y0, 0) per blur tile of one frame
+  int n_blur_items = 0;           // workgroups (8 strips) per frame
   int fast_lds_rows = 0;          // tallest cell of any level: sizes the dynamic LDS of k_fast_cells
   int n_slices = 1;               // slices a batch is cut into (ORBGPU_SLICES overrides)
   short *d_rs_strips = nullptr;   // k_resize_strips: (first dword, first row, dwords, 0) per strip, level after level
