@@ -250,6 +250,11 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
     // dependent rounds in levels x frames workgroups and leaves most of the chip idle
     // (enqueued after the quadtree so that the quadtree's workgroups are placed first and the blur fills the rest)
+    launch_quadtree_presort(ctx, fs, budget);
+    if (ctx->qt_ps_active && ctx->qt_ps_blur_late) {  // the blur starts beside the quadtree kernel, behind the presort
+      fork_ev = sev[0];
+      HIP_TRY(hipEventRecord(sev[0], fs.stream));
+    }
     if (launch_quadtree(ctx, fs, budget) != 0)
       return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
     if (timed) HIP_TRY(hipEventRecord(ev[4], fs.stream));
@@ -466,6 +471,22 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(dmalloc(&ctx->d_cands_tmp, B * g.cands_per_frame));
     HIP_TRY(dmalloc(&ctx->d_cell_prefix, B * g.cells_per_frame));
     if (qt_node_scratch) HIP_TRY(dmalloc(&ctx->d_qt_nodes, qt_node_scratch));
+    {
+      // levels from this many pixels on get the first rounds of their quadtree presorted by several workgroups
+      // (k_qt_presort); ORBGPU_QT_PRESORT_MINPX overrides (0: every level, negative: none)
+      const char *pm = std::getenv("ORBGPU_QT_PRESORT_MINPX");
+      const long long minpx = pm ? std::atoll(pm) : 400000;
+      ctx->qt_ps_levels = 0;
+      while (minpx >= 0 && ctx->qt_ps_levels < g.levels &&
+             (long long)g.lv[ctx->qt_ps_levels].w * g.lv[ctx->qt_ps_levels].h >= minpx)
+        ctx->qt_ps_levels++;
+      if (ctx->qt_ps_levels) HIP_TRY(dmalloc(&ctx->d_qt_ps, B * ctx->qt_ps_levels * quadtree_presort_words()));
+      // the blur then forks behind the presort launches, beside k_quadtree: forked behind FAST as usual it takes the
+      // chip first and the short presort launches wait for it to drain (4K: the scan launch 12 -> 320 us);
+      // ORBGPU_PS_BLUR=early restores that order (tuning aid)
+      const char *bl = std::getenv("ORBGPU_PS_BLUR");
+      ctx->qt_ps_blur_late = !(bl && bl[0] == 'e');
+    }
     // the error flag lives in pinned host memory that the device writes directly (only ever in the error case): no copy
     // per call -- a device-to-host copy of one int is a blit kernel of its own, 12 us between two kernels
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_error_flag), sizeof(int), hipHostMallocMapped));
@@ -496,7 +517,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count, ctx->d_kp_angle,
-                   ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes,
+                   ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes, ctx->d_qt_ps,
                    ctx->d_fast_groups, ctx->d_blur_strips, ctx->d_rs_strips};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);

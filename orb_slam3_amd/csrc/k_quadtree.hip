@@ -291,10 +291,12 @@ __device__ __forceinline__ unsigned f2(u64 v) { return (unsigned)((v >> 42) & 0x
 
 // write the children of parent P (quadrant counts c) into the new list: creation index `cidx` onwards, positions
 // counted from the back of the `ct` children (push_front order); multi-key children are appended to vs_new at `midx`
-__device__ void emit_children(const QShared &S, const QNode &P, const uint4 c, int cidx, int ct, int midx, int *max_child) {
+// flip: 1 when the division moved the keys into the other key buffer, 0 for the presorted rounds (keys stay where they are)
+__device__ void emit_children(const QShared &S, const QNode &P, const uint4 c, int cidx, int ct, int midx, int *max_child,
+                              unsigned flip) {
   int mx, my;
   node_mid(P, mx, my);
-  const unsigned nb = ((P.cnt >> 31) ^ 1u) << 31;
+  const unsigned nb = ((P.cnt >> 31) ^ flip) << 31;
   const unsigned cq[4] = {c.x, c.y, c.z, c.w};
   const unsigned short bx0[4] = {P.x0, (unsigned short)mx, P.x0, (unsigned short)mx};
   const unsigned short bx1[4] = {(unsigned short)mx, P.x1, (unsigned short)mx, P.x1};
@@ -335,7 +337,179 @@ struct QtArgs {
   int node_cap;                // LDS entries per list array
   int budget[ORBGPU_MAX_LEVELS];
   int nini[ORBGPU_MAX_LEVELS];
+  unsigned *ps;                // presort tables, PS_STRIDE words per (frame, presorted level)
+  int ps_levels;               // levels 0 .. ps_levels - 1 have tables
+  int ps_depth[ORBGPU_MAX_LEVELS];  // rounds of phase 1 the presort covers (0: that level is not presorted)
 };
+
+// ---- presort: the first rounds of phase 1 by several workgroups --------------------------------------------------
+// While nIni * 4^R <= nFeatures the list cannot reach the budget, so rounds 1..R of phase 1 divide EVERY multi-key node
+// (:356-423; after round k the list holds at most nIni * 4^k nodes, and phase 2 starts only when size + 3 * multi >
+// nFeatures).  R rounds of stable 4-way partitions order the keys by (root, quadrant path of depth R), stable inside a
+// path -- one stable counting sort by that code.  Several workgroups do it ahead of k_quadtree: a wave owns a
+// contiguous run of cells (candidate order = cells row-major, raster inside a cell), k_qt_presort<false> counts the codes of
+// every run, k_qt_presort_scan turns the counts into write positions and the per-code prefix `hpre`, k_qt_presort<true>
+// scatters the keys into key buffer B.  k_quadtree then runs its rounds 1..R without touching a key: the quadrant
+// counts of a node are differences of hpre over the code range of each child.  Keys are never ordered deeper than the
+// divisions that really happen, so the first-maximum rule inside a final node (:486-501) sees the reference's order.
+constexpr int PS_CHUNKS = 64;     // cell runs (one wave each) per (frame, level)
+constexpr int PS_NB_MAX = 1024;   // codes: nIni * 4^R
+constexpr int PS_STRIDE = PS_CHUNKS * PS_NB_MAX + PS_NB_MAX + 64;  // [chunk][code] counts / positions, then hpre[code]
+
+__device__ __forceinline__ int ps_code(unsigned key, float hX, int nIni, int H, int R) {
+  const int x = key_x(key), y = key_y(key);
+  const int b = nIni == 1 ? 0 : min(max((int)__fdiv_rn((float)x, hX), 0), nIni - 1);  // root strip, :329-333
+  int x0 = (int)__fmul_rn(hX, (float)b), x1 = (int)__fmul_rn(hX, (float)(b + 1)), y0 = 0, y1 = H;
+  int code = b;
+  for (int d = 0; d < R; d++) {
+    const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);  // node_mid
+    const int qx = x < mx ? 0 : 1, qy = y < my ? 0 : 1;
+    code = (code << 2) | qx | (qy << 1);
+    if (qx) x0 = mx; else x1 = mx;
+    if (qy) y0 = my; else y1 = my;
+  }
+  return code;
+}
+
+struct PsArgs {
+  const CellEntry *cells;
+  const unsigned *cands;
+  unsigned *buf_b;
+  unsigned *ps;
+  int ps_levels;
+  int depth[ORBGPU_MAX_LEVELS];
+  int nini[ORBGPU_MAX_LEVELS];
+};
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_qt_presort(DeviceGeom g, PsArgs a) {
+  __shared__ unsigned tab_all[4][PS_NB_MAX];
+  const int f = blockIdx.y, l = blockIdx.z;
+  const int R = a.depth[l];
+  if (R == 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, chunk = blockIdx.x * 4 + wave;
+  const LevelGeom L = g.lv[l];
+  const int nIni = a.nini[l], NB = nIni << (2 * R), nbits = 2 * R + 2;
+  const int W = L.w - 2 * ORB_MIN_BORDER, H = L.h - 2 * ORB_MIN_BORDER;
+  const float hX = __fdiv_rn((float)W, (float)nIni);
+  const int n_cells = L.ncols * L.nrows;
+  const int cpc = (n_cells + PS_CHUNKS - 1) / PS_CHUNKS;
+  const int c_beg = min(chunk * cpc, n_cells), c_end = min(c_beg + cpc, n_cells);
+  const CellEntry *cells = a.cells + (size_t)f * g.cells_per_frame + L.cell_off;
+  const size_t goff = (size_t)f * g.cands_per_frame + L.cand_off;
+  const unsigned *pool = a.cands + goff;
+  unsigned *dst = a.buf_b + goff;
+  unsigned *ps = a.ps + ((size_t)f * a.ps_levels + l) * PS_STRIDE;
+  unsigned *hist = ps + (size_t)chunk * PS_NB_MAX;
+  const unsigned *hpre = ps + (size_t)PS_CHUNKS * PS_NB_MAX;
+  volatile unsigned *tab = tab_all[wave];
+  for (int b = lane; b < NB; b += 64) tab[b] = SCATTER ? hist[b] + hpre[b] : 0u;
+  const u64 below = (1ull << lane) - 1ull;
+  const int slot = ((L.wcell + 1) >> 1) * ((L.hcell + 1) >> 1);
+
+  // 64 keys in candidate order (lane order), `have` marks the real ones
+  auto process = [&](unsigned key, bool have) {
+    const int code = have ? ps_code(key, hX, nIni, H, R) : 0;
+    if (!SCATTER) {
+      if (have) atomicAdd(&tab_all[wave][code], 1u);
+    } else {
+      u64 m = __ballot(have);
+      for (int bit = 0; bit < nbits; bit++) {
+        const bool one = (code >> bit) & 1;
+        const u64 bb = __ballot(one);
+        m &= one ? bb : ~bb;
+      }
+      if (have) {
+        const unsigned base = tab[code];
+        dst[base + (unsigned)__popcll(m & below)] = key;
+        if ((m >> lane) == 1ull) tab[code] = base + (unsigned)__popcll(m);  // the last lane of the code advances it
+      }
+    }
+  };
+
+  // 64 cells per step: lane = cell, a wave scan of the counts gives every cell's first position among the step's T
+  // candidates; then 64 candidates at a time, lane k finding its cell by bisection over the scanned counts (6 wave
+  // shuffles) -- every lane works whatever the cells hold, and the candidate loads of two steps are in flight together
+  for (int cb = c_beg; cb < c_end; cb += 64) {
+    const int c = cb + lane;
+    const int cnt = c < c_end ? cells[c].count : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    const int T = __shfl(incl, 63);
+    for (int k0 = 0; k0 < T; k0 += 128) {
+      unsigned key[2];
+      bool have[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int k = k0 + 64 * u + lane;
+        have[u] = k < T;
+        int j = 0;  // number of cells that end at or before k = the cell of candidate k
+#pragma unroll
+        for (int st = 32; st >= 1; st >>= 1)
+          if (__shfl(incl, j + st - 1) <= k) j += st;
+        j = min(j, 63);
+        const int first = __shfl(incl, j) - __shfl(cnt, j);
+        key[u] = have[u] ? pool[(size_t)(cb + j) * slot + (k - first)] : 0u;
+      }
+      process(key[0], have[0]);
+      if (k0 + 64 < T) process(key[1], have[1]);
+    }
+  }
+  if (!SCATTER)
+    for (int b = lane; b < NB; b += 64) hist[b] = tab[b];
+}
+
+// 256 threads (a 1024-thread workgroup waits for a whole CU's wave slots while the blur runs beside it)
+__global__ __launch_bounds__(256) void k_qt_presort_scan(PsArgs a) {
+  __shared__ u64 tot[PS_NB_MAX];
+  __shared__ u64 wsum[4];
+  const int f = blockIdx.x, l = blockIdx.y;
+  const int R = a.depth[l];
+  if (R == 0) return;
+  const int NB = a.nini[l] << (2 * R);
+  unsigned *ps = a.ps + ((size_t)f * a.ps_levels + l) * PS_STRIDE;
+  unsigned *hpre = ps + (size_t)PS_CHUNKS * PS_NB_MAX;
+  for (int b = threadIdx.x; b < PS_NB_MAX; b += 256) {
+    unsigned run = 0;
+    if (b < NB) {
+      unsigned t[PS_CHUNKS];
+#pragma unroll
+      for (int c = 0; c < PS_CHUNKS; c++) t[c] = ps[(size_t)c * PS_NB_MAX + b];
+#pragma unroll
+      for (int c = 0; c < PS_CHUNKS; c++) {
+        ps[(size_t)c * PS_NB_MAX + b] = run;
+        run += t[c];
+      }
+    }
+    tot[b] = run;
+  }
+  __syncthreads();
+  const u64 total = block_excl_scan<256>(tot, PS_NB_MAX, wsum);
+  for (int b = threadIdx.x; b < NB; b += 256) hpre[b] = (unsigned)tot[b];
+  if (threadIdx.x == 0) hpre[NB] = (unsigned)total;
+}
+
+// quadrant counts of the listed nodes (all of depth `rnd`) from the code prefix: no key moves
+__device__ __forceinline__ void presorted_counts(const QShared &S, const glb_u32 *keys, int Sz, int rnd, int R,
+                                                 const unsigned *hpre, float hX, int nIni, int H) {
+  const int sh = 2 * (R - rnd), s2 = sh - 2;
+  for (int i = threadIdx.x; i < Sz; i += blockDim.x) {
+    const QNode P = S.cur[i];
+    if ((P.cnt & 0x7fffffffu) <= 1) continue;
+    const int p = ps_code(keys[P.beg], hX, nIni, H, R) >> sh;
+    unsigned c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int lo = ((p << 2) | q) << s2;
+      c[q] = hpre[lo + (1 << s2)] - hpre[lo];
+    }
+    S.qc[i] = make_uint4(c[0], c[1], c[2], c[3]);
+  }
+}
 
 // Everything after the candidate count is known.  IN_LDS decides at compile time where the two key buffers live, so
 // that the partition loops use LDS instructions: with a run-time choice the pointers are generic and every key access
@@ -344,7 +518,8 @@ struct QtArgs {
 template <int NT, bool IN_LDS>
 __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, const LevelGeom &L, const int l, const int f,
                                        const int n, QShared S, unsigned *lds_keys, u64 *wsum, int *s_misc,
-                                       const CellEntry *cells, const int *cpre) {
+                                       const CellEntry *cells, const int *cpre, const int R = 0,
+                                       const unsigned *hpre = nullptr) {
   const int cap = a.node_cap;
   const int nF = a.budget[l];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -353,7 +528,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
   using KT = typename std::conditional<IN_LDS, lds_u32, glb_u32>::type;
   KT *keys0 = (KT *)(IN_LDS ? lds_keys : a.buf_a + goff);
   KT *keys1 = (KT *)(IN_LDS ? lds_keys + QT_LDS_KEYS : a.buf_b + goff);
-  {
+  if (R == 0) {  // (a presorted level has its keys in buffer B already)
     const unsigned *pool = a.cands + goff;
     KT *dst = keys0;
     // 16 lanes per cell, 16 cells per step, four steps in flight.  A cell's candidates sit in its fixed slot of the
@@ -387,7 +562,28 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
   const int nIni = a.nini[l];
   const float hX = __fdiv_rn((float)W, (float)nIni);
   int Sz = 0;  // list size
-  if (nIni == 1) {
+  if (!IN_LDS && R > 0) {
+    // presorted: the roots' keys are the code ranges [b * 4^R, (b + 1) * 4^R) of buffer B
+    if (tid == 0) {
+      int nroots = 0;
+      unsigned o = 0;
+      for (int b = 0; b < nIni; b++) {
+        const unsigned cb = hpre[(b + 1) << (2 * R)] - hpre[b << (2 * R)];
+        if (cb) {  // empty roots are erased (:343-344)
+          QNode r;
+          r.x0 = (unsigned short)(int)__fmul_rn(hX, (float)b);
+          r.x1 = (unsigned short)(int)__fmul_rn(hX, (float)(b + 1));
+          r.y0 = 0; r.y1 = (unsigned short)H;
+          r.beg = o; r.cnt = cb | 0x80000000u;
+          S.cur[nroots++] = r;
+        }
+        o += cb;
+      }
+      s_misc[0] = nroots;
+    }
+    __syncthreads();
+    Sz = s_misc[0];
+  } else if (nIni == 1) {
     if (tid == 0 && n > 0) {
       QNode r;
       r.x0 = 0; r.x1 = (unsigned short)(int)__fmul_rn(hX, 1.0f); r.y0 = 0; r.y1 = (unsigned short)H;
@@ -459,13 +655,21 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
   bool phase2 = false;
   int n_vs = 0;
   int max_cnt = n;  // upper bound of the key count of any node of the list
+  int rnd = 0;      // rounds done: the multi-key nodes of the list all have this depth
   while (!finish && !phase2) {
     if (a.prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.prof[15]++;
     const int prevSize = Sz;
     const int rr_ = a.prof ? min((int)a.prof[15] - 1, 3) : 0;
     if (a.prof) __syncthreads();
     STAMP(16 + 4 * rr_);
-    partition_nodes<NT, KT>(S, keys0, keys1, nullptr, Sz, max_cnt);
+    const bool presorted = !IN_LDS && rnd < R;
+    if constexpr (!IN_LDS) {
+      if (presorted) presorted_counts(S, keys1, Sz, rnd, R, hpre, hX, nIni, H);
+      else partition_nodes<NT, KT>(S, keys0, keys1, nullptr, Sz, max_cnt);
+    } else {
+      partition_nodes<NT, KT>(S, keys0, keys1, nullptr, Sz, max_cnt);
+    }
+    rnd++;
     __syncthreads();
     STAMP(17 + 4 * rr_);
     for (int i = tid; i < Sz; i += NT) {
@@ -485,7 +689,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     for (int i = tid; i < Sz; i += NT) {
       const QNode P = S.cur[i];
       const u64 pr = S.pre[i];
-      if ((P.cnt & 0x7fffffffu) > 1) emit_children(S, P, S.qc[i], (int)f0(pr), ct, (int)f2(pr), &s_misc[2]);
+      if ((P.cnt & 0x7fffffffu) > 1) emit_children(S, P, S.qc[i], (int)f0(pr), ct, (int)f2(pr), &s_misc[2], presorted ? 0u : 1u);
       else S.nxt[ct + (int)f1(pr)] = P;
     }
     __syncthreads();
@@ -567,7 +771,7 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     }
     for (int r = tid; r < nproc; r += NT) {
       const int i = S.vs[S.ord[r]];
-      emit_children(S, S.cur[i], S.qc[i], (int)f0(S.pre[r]), ct, (int)f2(S.pre[r]), nullptr);
+      emit_children(S, S.cur[i], S.qc[i], (int)f0(S.pre[r]), ct, (int)f2(S.pre[r]), nullptr, 1u);
     }
     for (int i = tid; i < Sz; i += NT)
       if (!S.flag[i]) S.nxt[ct + (int)S.pre2[i]] = S.cur[i];
@@ -645,6 +849,14 @@ __global__ __launch_bounds__(NT) void k_quadtree(DeviceGeom g, QtArgs a) {
   const CellEntry *cells = a.cells + (size_t)f * g.cells_per_frame + L.cell_off;
   int *cpre = a.cell_prefix + (size_t)f * g.cells_per_frame + L.cell_off;
   int n = 0;
+  const int R = blockIdx.y < a.ps_levels ? a.ps_depth[l] : 0;
+  if (R > 0) {
+    const unsigned *hpre = a.ps + ((size_t)f * a.ps_levels + l) * PS_STRIDE + (size_t)PS_CHUNKS * PS_NB_MAX;
+    n = (int)hpre[a.nini[l] << (2 * R)];
+    STAMP(1);
+    qt_run<NT, false>(g, a, L, l, f, n, S, lds_keys, wsum, s_misc, cells, cpre, R, hpre);
+    return;
+  }
   {
     int carry = 0;
     for (int base = 0; base < n_cells; base += NT) {
@@ -682,7 +894,38 @@ size_t quadtree_node_bytes(int node_cap) {
   const size_t b = (size_t)node_cap * (2 * sizeof(QNode) + sizeof(uint4) + 2 * sizeof(u64) + 3 * sizeof(unsigned short) + 1) + 64;
   return (b + 255) & ~(size_t)255;
 }
+size_t quadtree_presort_words() { return PS_STRIDE; }
 size_t quadtree_lds_bytes(int node_cap) { return sizeof(unsigned) * 2 * QT_LDS_KEYS + quadtree_node_bytes(node_cap); }
+
+void launch_quadtree_presort(orbgpu_ctx *c, FrameSlice fs, const int *budget) {
+  c->qt_ps_active = false;
+  if (c->qt_ps_levels <= 0 || !c->d_qt_ps) return;
+  const DeviceGeom &g = c->geom;
+  PsArgs pa{};
+  pa.cells = c->d_cells + (size_t)fs.f0 * g.cells_per_frame;
+  pa.cands = c->d_cands + (size_t)fs.f0 * g.cands_per_frame;
+  pa.buf_b = c->d_cands_tmp + (size_t)fs.f0 * g.cands_per_frame;
+  pa.ps = c->d_qt_ps + (size_t)fs.f0 * c->qt_ps_levels * PS_STRIDE;
+  pa.ps_levels = c->qt_ps_levels;
+  bool any = false;
+  for (int l = 0; l < c->qt_ps_levels; l++) {
+    int R = 0;
+    const int ni = c->nini[l];
+    if (ni <= 4) {  // the first round always runs (:356)
+      R = 1;
+      while ((ni << (2 * (R + 1))) <= budget[l] && (ni << (2 * (R + 1))) <= PS_NB_MAX) R++;
+    }
+    pa.depth[l] = c->qt_ps_depth[l] = R;
+    pa.nini[l] = ni;
+    any = any || R > 0;
+  }
+  if (!any) return;
+  c->qt_ps_active = true;
+  const dim3 pg(PS_CHUNKS / 4, fs.n, pa.ps_levels);
+  hipLaunchKernelGGL((k_qt_presort<false>), pg, dim3(256), 0, fs.stream, g, pa);
+  hipLaunchKernelGGL(k_qt_presort_scan, dim3(fs.n, pa.ps_levels), dim3(256), 0, fs.stream, pa);
+  hipLaunchKernelGGL((k_qt_presort<true>), pg, dim3(256), 0, fs.stream, g, pa);
+}
 
 int launch_quadtree(const orbgpu_ctx *c, FrameSlice fs, const int *budget) {
   const int n_frames = fs.n;
@@ -723,6 +966,13 @@ int launch_quadtree(const orbgpu_ctx *c, FrameSlice fs, const int *budget) {
   if (lds > 64 * 1024 && lds > c->qt_lds_configured[big]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
     c->qt_lds_configured[big] = lds;
+  }
+  a.ps = nullptr;
+  a.ps_levels = 0;
+  if (c->qt_ps_active) {
+    a.ps = c->d_qt_ps + (size_t)fs.f0 * c->qt_ps_levels * PS_STRIDE;
+    a.ps_levels = c->qt_ps_levels;
+    for (int l = 0; l < c->qt_ps_levels; l++) a.ps_depth[l] = c->qt_ps_depth[l];
   }
   a.prof = nullptr;
   const bool profile = getenv("ORBGPU_QT_PROFILE") != nullptr;

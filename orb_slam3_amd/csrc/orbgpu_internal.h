@@ -129,6 +129,11 @@ struct orbgpu_ctx {
   unsigned *d_cands_tmp = nullptr;     // key buffer B of the device quadtree (levels too large for LDS)
   int *d_cell_prefix = nullptr;        // [frame][cells_per_frame]
   unsigned char *d_qt_nodes = nullptr; // [frame][level] node arrays of the quadtree kernel when they do not fit LDS
+  unsigned *d_qt_ps = nullptr;         // [frame][qt_ps_levels] presort tables of the quadtree (k_qt_presort), big levels only
+  int qt_ps_levels = 0;                // leading levels whose first quadtree rounds are presorted by several workgroups
+  int qt_ps_depth[ORBGPU_MAX_LEVELS]{}; // rounds covered per level for the call being enqueued (launch_quadtree_presort)
+  bool qt_ps_active = false;           // that call presorted at least one level
+  bool qt_ps_blur_late = true;         // the blur forks behind the presort launches instead of behind FAST
   int *d_error_flag = nullptr;         // set by kernels on capacity violations
   int *h_error_flag = nullptr;
   short2 *d_kp_xy = nullptr;      // [frame][kps_per_frame] level coordinates after the quadtree
@@ -202,10 +207,13 @@ void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t fr
 
 // device quadtree (k_quadtree.hip); budget = per-level feature budget.  Returns 0 or -1 (LDS too large)
 int launch_quadtree(const orbgpu_ctx *c, FrameSlice fs, const int *budget);
+// the three presort launches ahead of it (no-op for contexts without presorted levels); sets qt_ps_depth / qt_ps_active
+void launch_quadtree_presort(orbgpu_ctx *c, FrameSlice fs, const int *budget);
 size_t quadtree_lds_bytes(int node_cap);
 // dynamic LDS the quadtree kernel may ask for: the CU's 160 KB less its static arrays (scan sums, partition counters)
 constexpr size_t ORBGPU_QT_LDS_LIMIT = 156 * 1024;
 size_t quadtree_node_bytes(int node_cap);
+size_t quadtree_presort_words();  // u32 words of presort tables per (frame, presorted level)
 
 
 // matching
