@@ -209,3 +209,30 @@ def test_resize_kernels_agree(oracle, monkeypatch):
         _kp_equal(ft.keypoints, okp)
         assert np.array_equal(ft.descriptors, odesc)
         fe.close()
+
+
+@pytest.mark.parametrize("w,h,nfeat,levels,seed,scene", [
+    (640, 480, 1000, 8, 31, "rich"),       # nIni = 1, three presorted rounds on level 0
+    (640, 480, 30, 8, 32, "rich"),         # tiny budgets: one presorted round, the list stops right behind it
+    (640, 480, 6000, 8, 33, "rich"),       # budget above the candidates: every node ends as a singleton
+    (1280, 720, 3000, 8, 34, "rich"),      # nIni = 2, keys in the global buffers
+    (800, 300, 1200, 5, 35, "rich"),       # nIni = 3: a code range that is not a power of two
+    (1100, 200, 900, 3, 36, "rich"),       # nIni = 6: those levels are not presorted, the others are
+    (640, 480, 1000, 8, 37, "checker"),    # exact ties: equal responses inside a node (first maximum by candidate order)
+    (640, 480, 2000, 8, 38, "noise"),      # cells with far more than 16 candidates
+    (640, 480, 800, 8, 39, "gradient"),    # most cells and most codes empty
+])
+def test_extract_quadtree_presorted(oracle, monkeypatch, w, h, nfeat, levels, seed, scene):
+    """the presort of the quadtree's first rounds (k_qt_presort, by default for levels of 0.4 Mpx and more) forced for
+    every level: keypoints and descriptors against the oracle, and identical to the plain kernel"""
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    img = _scene(scene, seed, h, w)
+    okp, odesc = oracle.extract_literal(oracle.params(w, h, levels=levels), img, nfeat)
+    for minpx in ("0", "-1"):
+        monkeypatch.setenv("ORBGPU_QT_PRESORT_MINPX", minpx)
+        fe = ORBFeatureExtractor(w, h, 1.2, levels, 20, 7, max_features=nfeat)
+        ft = Features(w, h)
+        assert fe.Extract(img, ft, nfeat) == 0
+        _kp_equal(ft.keypoints, okp)
+        assert np.array_equal(ft.descriptors, odesc)
+        fe.close()
