@@ -95,7 +95,7 @@ struct FastGroup { short level, row, j0, ncell; };  // cells j0 .. j0 + ncell - 
 constexpr int FC_TP = 36;               // dwords per staged / score row (<= 33 quads + 2 apron dwords)
 constexpr int FC_TPB = FC_TP * 4;
 constexpr int FC_MAXK = 4;              // cells per group
-constexpr int FC_QPITCH = 136;          // queue entries per row (<= 33 quads x 4 pixels)
+constexpr int FC_QPITCH = 128;          // queue entries per row: only pixels of the cells are pushed, <= 128 per row (with 136 a 33-row launch took 20.8 KB, 7 workgroups per CU)
 constexpr int FC_MAXROWS = 64;          // rows of a cell (hcell <= 64 is checked at create time)
 
 __host__ __device__ constexpr size_t fast_cells_lds_bytes(int rows) {
