@@ -443,6 +443,50 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       if (!rs.empty()) HIP_TRY(hipMemcpy(ctx->d_rs_strips, rs.data(), rs.size() * sizeof(short), hipMemcpyHostToDevice));
     }
     {
+      // opt-in: small levels at the end of the pyramid built two or three per launch (k_resize_nest): levels below
+      // ORBGPU_RESIZE_NEST_MAXPX pixels (default 0: none), or the explicit plan ORBGPU_RESIZE_NEST="src:n,src:n".
+      // Measured on the 256-frame VGA batch: levels 5-7 in one launch take as long as their three launches do beside
+      // level 0's FAST groups (pyramid stage 0.229 ms either way), so the default stays one launch per level
+      for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) ctx->rs_nest_of[l] = -1;
+      ctx->n_rs_nest = 0;
+      std::vector<std::pair<int, int>> plan;
+      if (const char *np = std::getenv("ORBGPU_RESIZE_NEST")) {
+        int a = 0, b = 0, used = 0;
+        while (std::sscanf(np, "%d:%d%n", &a, &b, &used) == 2) {
+          plan.push_back({a, b});
+          np += used;
+          if (*np == ',') np++;
+        }
+      } else {
+        const char *mp = std::getenv("ORBGPU_RESIZE_NEST_MAXPX");
+        const long long maxpx = mp ? std::atoll(mp) : 0;
+        int s0 = g.levels;
+        while (s0 > 1 && (long long)g.lv[s0 - 1].w * g.lv[s0 - 1].h < maxpx) s0--;
+        int count = g.levels - s0;
+        while (count >= 2 && (int)plan.size() < 4) {
+          const int nl = count == 4 ? 2 : std::min(3, count);
+          plan.push_back({s0 - 1, nl});
+          s0 += nl;
+          count -= nl;
+        }
+      }
+      for (auto &pl : plan) {
+        if (ctx->n_rs_nest >= 4) break;
+        bool clash = pl.first < 0 || pl.second < 2 || pl.first + pl.second > g.levels - 1;
+        for (int q = 1; !clash && q <= pl.second; q++) clash = ctx->rs_nest_of[pl.first + q] >= 0;
+        if (clash) continue;
+        ResizeNest &n = ctx->rs_nest[ctx->n_rs_nest];
+        std::vector<short> xr, yr;
+        if (!build_resize_nest(g, xt.data(), yt.data(), pl.first, pl.second, n, xr, yr)) continue;
+        HIP_TRY(dmalloc(&n.d_xr, xr.size()));
+        HIP_TRY(dmalloc(&n.d_yr, yr.size()));
+        HIP_TRY(hipMemcpy(n.d_xr, xr.data(), xr.size() * sizeof(short), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(n.d_yr, yr.data(), yr.size() * sizeof(short), hipMemcpyHostToDevice));
+        for (int q = 1; q <= pl.second; q++) ctx->rs_nest_of[pl.first + q] = ctx->n_rs_nest;
+        ctx->n_rs_nest++;
+      }
+    }
+    {
       std::vector<short> groups;
       ctx->n_fast_groups = build_fast_groups(g, groups);
       for (int l = 0; l < g.levels; l++) ctx->fast_lds_rows = std::max(ctx->fast_lds_rows, g.lv[l].hcell);
@@ -521,6 +565,10 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
                    ctx->d_fast_groups, ctx->d_blur_strips, ctx->d_rs_strips};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
+  for (auto &n : ctx->rs_nest) {
+    if (n.d_xr) (void)hipFree(n.d_xr);
+    if (n.d_yr) (void)hipFree(n.d_yr);
+  }
   void *hptrs[] = {ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};
   for (void *p : hptrs)
     if (p) (void)hipHostFree(p);

@@ -425,6 +425,111 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two or three SMALL pyramid levels in one launch.  The last levels of a VGA pyramid hold 25-70 k
+// pixels: their launches are bound by ramp-up and by waiting for the predecessor, not by bytes.  Here a workgroup owns
+// a 64 x 32 tile of the LAST level of the nest and everything that tile descends from: it stages the footprint of the
+// nest's source level in LDS, builds the region of the next level it needs (plus the part of that level it OWNS: the
+// levels in between are partitioned among the tiles by following the tiles' first columns / rows down the tables) into
+// LDS and global memory, then the next from that.  Regions of neighbouring tiles overlap by the bilinear halo (one
+// or two pixels per level); a pixel is computed from the same table entries whoever computes it, so the overlap is
+// redundant work, not a difference.  The regions are computed on the host from the same tables (build_resize_nest).
+// Same arithmetic as k_resize_level.
+struct NestDev {
+  int src_level, nl, ntx, nty;
+  int pitch[3], off[3];   // LDS rows of the source region and of the first nl - 1 built regions
+  int xoff[4], yoff[4];   // LDS offsets of the staged column / row coefficients of level src + q, q = 1 .. nl
+  const short4 *xr, *yr;  // [tile column / row][q = 0 .. nl]: (first, last) of the region and of the owned part, level src + q
+};
+
+__global__ __launch_bounds__(256) void k_resize_nest(uint8_t *__restrict__ pyr, DeviceGeom g, NestDev a,
+                                                     const XTab *__restrict__ xtab, const YTab *__restrict__ ytab,
+                                                     int n_frames, Level0Src lvl0) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t nest_lds[];
+  int t, f;
+  if (!xcd_item_frame(a.ntx * a.nty, n_frames, t, f)) return;
+  const int tyi = t / a.ntx, txi = t - tyi * a.ntx;
+  const short4 *xr = a.xr + txi * (a.nl + 1), *yr = a.yr + tyi * (a.nl + 1);
+  {
+    const LevelGeom S = g.lv[a.src_level];
+    const uint8_t *src = level_src(pyr, g, lvl0, f, a.src_level, S.off);
+    const short4 X = xr[0], Y = yr[0];
+    const int ncols16 = (X.y - X.x) / 16 + 1, nrows = Y.y - Y.x + 1;
+    const float inv = 1.0f / (float)ncols16;
+    for (int i = threadIdx.x; i < nrows * ncols16; i += 256) {
+      int r = (int)((float)i * inv);
+      int c = i - r * ncols16;
+      if (c < 0) { r--; c += ncols16; }
+      if (c >= ncols16) { r++; c -= ncols16; }
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (X.x + 16 * c < S.pitch) v = *reinterpret_cast<const uint4 *>(src + (size_t)(Y.x + r) * S.pitch + X.x + 16 * c);
+      *reinterpret_cast<uint4 *>(&nest_lds[a.off[0] + r * a.pitch[0] + 16 * c]) = v;
+    }
+    // the coefficients of every level's region, relative to the region below it: columns (sx0 - first column,
+    // a0 | a1 << 16), rows (byte offsets of the two source rows, b0 | b1 << 16)
+    for (int q = 1; q <= a.nl; q++) {
+      const LevelGeom D = g.lv[a.src_level + q];
+      const short4 Xq = xr[q], Yq = yr[q], PX = xr[q - 1], PY = yr[q - 1];
+      const int ncol = ((Xq.y - Xq.x) / 4 + 1) * 4, nrow = Yq.y - Yq.x + 1;
+      uint2 *xs = reinterpret_cast<uint2 *>(nest_lds + a.xoff[q]);
+      uint4 *ys = reinterpret_cast<uint4 *>(nest_lds + a.yoff[q]);
+      for (int i = threadIdx.x; i < ncol; i += 256) {
+        const XTab e = xtab[D.xtab_off + min(Xq.x + i, D.w - 1)];
+        xs[i] = make_uint2((unsigned)(e.sx0 - PX.x), (unsigned)(unsigned short)e.a0 | ((unsigned)(unsigned short)e.a1 << 16));
+      }
+      for (int i = threadIdx.x; i < nrow; i += 256) {
+        const YTab e = ytab[D.ytab_off + Yq.x + i];
+        ys[i] = make_uint4((unsigned)((e.sy0 - PY.x) * a.pitch[q - 1]), (unsigned)((e.sy1 - PY.x) * a.pitch[q - 1]),
+                           (unsigned)(unsigned short)e.b0 | ((unsigned)(unsigned short)e.b1 << 16), 0u);
+      }
+    }
+  }
+  __syncthreads();
+  const int cg0 = threadIdx.x & 31, rsub = threadIdx.x >> 5;  // 32 pixel quads x 8 rows per step
+  for (int q = 1; q <= a.nl; q++) {
+    const LevelGeom D = g.lv[a.src_level + q];
+    const short4 X = xr[q], Y = yr[q];
+    const uint8_t *in = nest_lds + a.off[q - 1];
+    uint8_t *out = q < a.nl ? nest_lds + a.off[q] : nullptr;
+    const int op = q < a.nl ? a.pitch[q] : 0;
+    uint8_t *dst = pyr + (size_t)f * g.frame_bytes + D.off;
+    const int ncg = (X.y - X.x) / 4 + 1, nrows = Y.y - Y.x + 1;  // X.x is a multiple of 4
+    const uint2 *xs = reinterpret_cast<const uint2 *>(nest_lds + a.xoff[q]);
+    const uint4 *ys = reinterpret_cast<const uint4 *>(nest_lds + a.yoff[q]);
+    for (int cg = cg0; cg < ncg; cg += 32) {
+      const int dx = X.x + 4 * cg;
+      unsigned cx[4], ca0[4], ca1[4], keep = 0;
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const uint2 e = xs[4 * cg + p];
+        cx[p] = e.x;
+        ca0[p] = e.y & 0xffffu;
+        ca1[p] = e.y >> 16;
+        if (dx + p < D.w) keep |= 0xffu << (8 * p);
+      }
+      const bool own_x = dx >= X.z && dx <= X.w;
+      for (int r = rsub; r < nrows; r += 8) {
+        const uint4 yy = ys[r];
+        const uint8_t *r0 = in + yy.x, *r1 = in + yy.y;
+        const unsigned b0 = yy.z & 0xffffu, b1 = yy.z >> 16;
+        unsigned val = 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const unsigned s00 = r0[cx[p]], s01 = r0[cx[p] + 1], s10 = r1[cx[p]], s11 = r1[cx[p] + 1];
+          const unsigned h0 = mad24u(s01, ca1[p], mul24u(s00, ca0[p]));
+          const unsigned h1 = mad24u(s11, ca1[p], mul24u(s10, ca0[p]));
+          const unsigned v = ((mul24u(b0, h0 >> 4) >> 16) + (mul24u(b1, h1 >> 4) >> 16) + 2) >> 2;
+          val |= (v & 255u) << (8 * p);
+        }
+        const int dy = Y.x + r;
+        if (out) *reinterpret_cast<unsigned *>(out + r * op + 4 * cg) = val;
+        if (own_x && dy >= Y.z && dy <= Y.w) *reinterpret_cast<unsigned *>(dst + (size_t)dy * D.pitch + dx) = val & keep;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t frame_stride, int stride, int n_frames) {
@@ -435,8 +540,109 @@ void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t fr
                      c->geom.frame_bytes, L.w, L.h, L.pitch, aligned16);
 }
 
+
+// regions of k_resize_nest for the levels src + 1 .. src + nl, tiles of NEST_TW x NEST_TH pixels of the last one.
+// Per tile column (and, with the row tables, per tile row) and level q: the region [lo, hi] the workgroup builds and the
+// part [own_lo, own_hi] of it that it writes to global memory.  The owned parts partition every level: their first
+// columns follow the tiles' first columns down the tables (rounded down to a dword), and a region is the hull of what
+// the next level's region reads and of the owned part.  Returns false when a region does not fit the 16-bit fields.
+constexpr int NEST_TW = 64, NEST_TH = 32;
+static void nest_axis(const DeviceGeom &g, int src, int nl, bool is_x, const XTab *xt, const YTab *yt, int tile,
+                      std::vector<short> &tab, int *extent /* [nl + 1]: largest region extent of level src + q */) {
+  auto size_of = [&](int q) { return is_x ? g.lv[src + q].w : g.lv[src + q].h; };
+  auto lo_of = [&](int q, int v) {  // first source index (level src + q - 1) read by index v of level src + q
+    return is_x ? xt[g.lv[src + q].xtab_off + v].sx0 : yt[g.lv[src + q].ytab_off + v].sy0;
+  };
+  auto hi_of = [&](int q, int v) {
+    return is_x ? std::min(xt[g.lv[src + q].xtab_off + v].sx0 + 1, size_of(q - 1) - 1) : yt[g.lv[src + q].ytab_off + v].sy1;
+  };
+  const int n_last = size_of(nl), nt = (n_last + tile - 1) / tile;
+  // chain of first owned indices: c[q][i], i = 0 .. nt
+  std::vector<std::vector<int>> c(nl + 1, std::vector<int>(nt + 1));
+  for (int i = 0; i <= nt; i++) c[nl][i] = std::min(i * tile, n_last);
+  for (int q = nl - 1; q >= 1; q--) {
+    for (int i = 0; i < nt; i++) {
+      int v = i == 0 ? 0 : lo_of(q + 1, c[q + 1][i]);
+      if (is_x) v &= ~3;
+      c[q][i] = v;
+    }
+    c[q][nt] = size_of(q);
+  }
+  for (int q = 0; q <= nl; q++) extent[q] = 0;
+  tab.assign((size_t)nt * (nl + 1) * 4, 0);
+  for (int i = 0; i < nt; i++) {
+    int lo = c[nl][i], hi = c[nl][i + 1] - 1;
+    short *e = &tab[((size_t)i * (nl + 1) + nl) * 4];
+    e[0] = (short)lo; e[1] = (short)hi; e[2] = (short)lo; e[3] = (short)hi;
+    extent[nl] = std::max(extent[nl], hi - lo + 1);
+    for (int q = nl - 1; q >= 0; q--) {
+      int nlo = lo_of(q + 1, lo), nhi = hi_of(q + 1, hi);
+      int olo = 0, ohi = -1;
+      if (q >= 1) {
+        olo = c[q][i];
+        ohi = c[q][i + 1] - 1;
+        if (ohi >= olo) { nlo = std::min(nlo, olo); nhi = std::max(nhi, ohi); }
+        if (is_x) nlo &= ~3;
+      } else if (is_x) {
+        nlo &= ~15;
+        nhi = xt[g.lv[src + 1].xtab_off + hi].sx0 + 1;  // unclamped: the staging loop guards the pitch, the weight there is 0
+      }
+      lo = nlo; hi = nhi;
+      e = &tab[((size_t)i * (nl + 1) + q) * 4];
+      e[0] = (short)lo; e[1] = (short)hi; e[2] = (short)olo; e[3] = (short)ohi;
+      extent[q] = std::max(extent[q], hi - lo + 1);
+    }
+  }
+}
+
+bool build_resize_nest(const DeviceGeom &g, const XTab *xt, const YTab *yt, int src, int nl, ResizeNest &n,
+                       std::vector<short> &xr, std::vector<short> &yr) {
+  if (nl < 2 || nl > 3 || src < 0 || src + nl > g.levels - 1) return false;
+  int ex[4] = {0, 0, 0, 0}, ey[4] = {0, 0, 0, 0};
+  nest_axis(g, src, nl, true, xt, yt, NEST_TW, xr, ex);
+  nest_axis(g, src, nl, false, xt, yt, NEST_TH, yr, ey);
+  n.src_level = src;
+  n.nl = nl;
+  n.ntx = (g.lv[src + nl].w + NEST_TW - 1) / NEST_TW;
+  n.nty = (g.lv[src + nl].h + NEST_TH - 1) / NEST_TH;
+  size_t off = 0;
+  for (int q = 0; q < nl; q++) {
+    // a pixel quad beyond the region's last column still reads its (unused) sources: 16 bytes of slack per row
+    n.pitch[q] = ((ex[q] + 15) & ~15) + 16;
+    n.off[q] = (int)off;
+    off += (size_t)n.pitch[q] * (ey[q] + 1);
+  }
+  for (int q = 1; q <= nl; q++) {  // staged coefficients: 8 bytes per column (quads rounded up), 16 per row
+    off = (off + 15) & ~(size_t)15;
+    n.xoff[q] = (int)off;
+    off += (size_t)(ex[q] + 8) * 8;
+    off = (off + 15) & ~(size_t)15;
+    n.yoff[q] = (int)off;
+    off += (size_t)(ey[q] + 1) * 16;
+  }
+  n.lds = off;
+  return off <= 60 * 1024;
+}
+
+void launch_resize_nest(const orbgpu_ctx *c, FrameSlice fs, const ResizeNest &n) {
+  NestDev a{};
+  a.src_level = n.src_level; a.nl = n.nl; a.ntx = n.ntx; a.nty = n.nty;
+  for (int q = 0; q < 3; q++) { a.pitch[q] = n.pitch[q]; a.off[q] = n.off[q]; }
+  for (int q = 0; q < 4; q++) { a.xoff[q] = n.xoff[q]; a.yoff[q] = n.yoff[q]; }
+  a.xr = reinterpret_cast<const short4 *>(n.d_xr);
+  a.yr = reinterpret_cast<const short4 *>(n.d_yr);
+  dim3 grid(n.ntx * n.nty * xcd_frames(fs.n));
+  hipLaunchKernelGGL(k_resize_nest, grid, dim3(256), n.lds, fs.stream, c->d_pyr + (size_t)fs.f0 * c->geom.frame_bytes, c->geom, a,
+                     c->d_xtab, c->d_ytab, fs.n, slice_lvl0(c, fs));
+}
+
 void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level) {
   const LevelGeom &D = c->geom.lv[level];
+  if (c->rs_nest_of[level] >= 0) {  // built by a nest: launched with the nest's first level
+    const ResizeNest &n = c->rs_nest[c->rs_nest_of[level]];
+    if (level == n.src_level + 1) launch_resize_nest(c, fs, n);
+    return;
+  }
   if (c->rs_items[level] > 0) {
     dim3 grid(c->rs_items[level] * xcd_frames(fs.n));
     hipLaunchKernelGGL(k_resize_strips, grid, dim3(256), 0, fs.stream, c->d_pyr + (size_t)fs.f0 * c->geom.frame_bytes, c->geom,

@@ -87,6 +87,15 @@ __device__ __forceinline__ int usable_count(int n, int capacity) { return (n < 0
     if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr, __FILE__, __LINE__);    \
   } while (0)
 
+// two or three small pyramid levels built by one launch (k_resize_nest)
+struct ResizeNest {
+  int src_level = 0, nl = 0, ntx = 0, nty = 0;
+  int pitch[3]{}, off[3]{};
+  int xoff[4]{}, yoff[4]{};
+  size_t lds = 0;
+  short *d_xr = nullptr, *d_yr = nullptr;
+};
+
 struct orbgpu_ctx {
   orbgpu_params params{};
   DeviceGeom geom{};
@@ -121,6 +130,9 @@ struct orbgpu_ctx {
   int n_slices = 1;               // slices a batch is cut into (ORBGPU_SLICES overrides)
   short *d_rs_strips = nullptr;   // k_resize_strips: (first dword, first row, dwords, 0) per strip, level after level
   int rs_strip_off[ORBGPU_MAX_LEVELS]{}, rs_items[ORBGPU_MAX_LEVELS]{};  // first strip / workgroups per frame (0: k_resize_level)
+  ResizeNest rs_nest[4];
+  int n_rs_nest = 0;
+  int rs_nest_of[ORBGPU_MAX_LEVELS]{};  // nest that builds the level, or -1
   XTab *d_xtab = nullptr;
   YTab *d_ytab = nullptr;
   CellEntry *d_cells = nullptr;   // [frame][cells_per_frame]
@@ -191,6 +203,8 @@ inline Level0Src slice_lvl0(const orbgpu_ctx *c, FrameSlice fs) {
   return c->lvl0.base ? Level0Src{c->lvl0.base + (size_t)fs.f0 * (size_t)c->lvl0.frame_stride, c->lvl0.frame_stride} : c->lvl0;
 }
 void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level);
+bool build_resize_nest(const DeviceGeom &g, const XTab *xt, const YTab *yt, int src, int nl, ResizeNest &n,
+                       std::vector<short> &xr, std::vector<short> &yr);
 // fused FAST score + cell NMS (k_fast.hip); score_dump != nullptr: also scatter the non-zero scores into that slab
 // (laid out like the slice: its frame 0 is frame f0 of the batch)
 int build_fast_groups(const DeviceGeom &g, std::vector<short> &table);

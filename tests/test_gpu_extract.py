@@ -236,3 +236,25 @@ def test_extract_quadtree_presorted(oracle, monkeypatch, w, h, nfeat, levels, se
         _kp_equal(ft.keypoints, okp)
         assert np.array_equal(ft.descriptors, odesc)
         fe.close()
+
+
+@pytest.mark.parametrize("w,h,plan", [(640, 480, "4:3"), (640, 480, "3:2,5:2"), (517, 389, "2:3,5:2"),
+                                      (752, 480, "1:3,4:3"), (320, 240, "0:2")])
+def test_resize_nest_agrees(oracle, monkeypatch, w, h, plan):
+    """two or three pyramid levels per launch (k_resize_nest, opt-in): the pyramid levels are byte-identical to the
+    oracle's, and so are keypoints and descriptors"""
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    levels = 8 if w >= 500 else 5
+    img = synth.frame(91, h, w)
+    p = oracle.params(w, h, 1.2, levels, 20, 7)
+    okp, odesc, ex = oracle.extract(p, img, 800, dump=True)
+    monkeypatch.setenv("ORBGPU_RESIZE_NEST", plan)
+    fe = ORBFeatureExtractor(w, h, 1.2, levels, 20, 7, max_features=800)
+    ft = Features(w, h)
+    assert fe.Extract(img, ft, 800) == 0
+    g = ex["geometry"]
+    for l, (a, b) in enumerate(zip(_levels(fe.debug_dump()["pyramid"], g), _levels(ex["pyramid"], g))):
+        assert np.array_equal(a, b), f"pyramid level {l}"
+    _kp_equal(ft.keypoints, okp)
+    assert np.array_equal(ft.descriptors, odesc)
+    fe.close()
