@@ -353,10 +353,13 @@ def test_caller_stream_and_capacity_flag(oracle):
     fe.close()
 
 
-@pytest.mark.parametrize("switch", ["ORBGPU_EARLY_L0=0", "ORBGPU_NO_OVERLAP=1", "ORBGPU_RESIZE=tiles", "slices=2"])
+@pytest.mark.parametrize("switch", ["ORBGPU_EARLY_L0=0", "ORBGPU_NO_OVERLAP=1", "ORBGPU_RESIZE=tiles", "slices=2",
+                                    "ORBGPU_QT_PRESORT_MINPX=0", "ORBGPU_QT_PRESORT_MINPX=0;slices=2",
+                                    "ORBGPU_QT_PRESORT_MINPX=0;ORBGPU_PS_BLUR=early", "ORBGPU_RESIZE_NEST=4:3"])
 def test_schedules_give_identical_results(monkeypatch, switch):
     """the stage schedule (level 0's FAST launch beside the resize chain, blur beside quadtree and orientation, frame
-    slices) and the resize kernel are choices of speed only: each alternative writes the same bytes as the default"""
+    slices), the resize kernels and the quadtree presort are choices of speed only: each alternative writes the same
+    bytes as the default"""
     import torch
     from orb_slam3_amd import _lib
     from orb_slam3_amd.features import ORBFeatureExtractor
@@ -367,11 +370,15 @@ def test_schedules_give_identical_results(monkeypatch, switch):
     d_imgs = torch.from_numpy(frames).to(dev)
 
     def run(env):
-        if env and "=" in env and not env.startswith("slices"):
-            k, v = env.split("=")
-            monkeypatch.setenv(k, v)
+        parts = env.split(";") if env else []
+        keys = []
+        for part in parts:
+            if not part.startswith("slices"):
+                k, v = part.split("=")
+                monkeypatch.setenv(k, v)
+                keys.append(k)
         fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_batch=B, max_features=NF)
-        if env == "slices=2":
+        if "slices=2" in parts:
             assert lib.orbgpu_set_batch_slices(fe.handle, 2) == 0
         cap = fe.geometry(NF).keypoint_capacity
         d_kp = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
@@ -385,8 +392,8 @@ def test_schedules_give_identical_results(monkeypatch, switch):
         assert lib.orbgpu_synchronize(fe.handle) == 0
         out = d_kp.cpu().numpy(), d_desc.cpu().numpy(), d_n.cpu().numpy()
         fe.close()
-        if env and "=" in env and not env.startswith("slices"):
-            monkeypatch.delenv(env.split("=")[0])
+        for k in keys:
+            monkeypatch.delenv(k)
         return out
 
     ref = run(None)
