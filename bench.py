@@ -149,9 +149,13 @@ def main():
     ap.add_argument("--no-allpairs", action="store_true", help="skip the keyframe all-pairs section (SURVEY 8e)")
     ap.add_argument("--keyframe-every", type=int, default=4)
     ap.add_argument("--no-database", action="store_true", help="skip the keyframe-database query section (SURVEY 8f.4)")
-    ap.add_argument("--host-path", action="store_true",
-                    help="also measure the PCIe-inclusive host-pointer entry points (off by default: their launches on 1 and "
-                         "256 frames would be averaged into the per-kernel statistics of a profiled run)")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the PCIe-inclusive host-pointer entry points (single-frame Extract, one window search, a "
+                         "256-frame host batch); a profiled run skips them so that their launches are not averaged into the "
+                         "per-kernel statistics of the batch kernels")
+    ap.add_argument("--no-sequence", action="store_true", help="skip the offline sequence section (BASELINE configs[4])")
+    ap.add_argument("--sequence-frames", type=int, default=20000,
+                    help="frames of the offline sequence, sharded by block over the ranks (configs[4]: 20,000)")
     ap.add_argument("--no-large", action="store_true", help="skip the 1920x1080 / 3840x2160 section (BASELINE configs[2])")
     ap.add_argument("--no-projection", action="store_true", help="skip the search-by-projection matching section")
     ap.add_argument("--dry-run", action="store_true",
@@ -339,6 +343,71 @@ def main():
                     "exchange": (f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})"
                                  if world > 1 else "none (1 rank)"),
                     "matches_rank0": int(nm.sum().item()), "includes": "all-gather + match + rotation filter, max over ranks"}
+
+    # ---- BASELINE.json configs[4]: the offline sequence, block-sharded over the ranks ------------------------------
+    # every rank streams ITS block of the sequence through the extractor in batches of B frames (uploads on a copy stream
+    # through a ring of device buffers, links across batch and rank boundaries, every 10th frame kept as a keyframe),
+    # then ONE all-gather and the all-pairs keyframe matching (rows = own keyframes).  Two legs: frames crossing PCIe
+    # from pinned host memory, and the same loop fed from an HBM-resident pool.  Reported beside `value`, never in it.
+    sequence = None
+    if not args.no_sequence and headline:
+        from orb_slam3_amd.sequence import PooledSource, ResidentSource, SequenceRunner
+        n_seq = args.sequence_frames
+        pooled = PooledSource(1240, pool_frames=64, height=H, width=W)
+        legs = {}
+        kf_result = None
+        for leg, src in (("pcie_inclusive", pooled), ("hbm_resident", ResidentSource(pooled, dev))):
+            runner = SequenceRunner(fe, src, NF, keyframe_every=10)
+            runner.run(min(n_seq, 3 * B), rank, world)            # warm-up: scratch, ring, events
+            best = None
+            for it in range(2):
+                barrier()
+                res = runner.run(n_seq, rank, world)
+                barrier()
+                tt = torch.tensor([res.timing["seconds"]], dtype=torch.float64, device=dev)
+                if world > 1:
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                if best is None or float(tt.item()) < best[0]:
+                    best = (float(tt.item()), res)
+            sec, res = best
+            legs[leg] = {"seconds": round(sec, 4), "frames_per_s": round(n_seq / sec, 1),
+                         "frames_extracted_rank0": res.timing["frames_extracted"], "batches_rank0": res.timing["batches"],
+                         "host_enqueue_seconds_rank0": round(res.timing["enqueue_seconds"], 4)}
+            if leg == "pcie_inclusive":
+                legs[leg]["upload_GBps_per_gpu"] = round(res.timing["bytes_uploaded"] / sec / 1e9, 2)
+                legs[leg]["source"] = "64 procedural frames in pinned host memory, frame i = pool[i % 64]; every frame crosses PCIe"
+                kf_result, kf_runner = res, runner
+            del runner
+        # all-pairs over the keyframes of the PCIe leg's result
+        barrier()
+        t1 = time.perf_counter()
+        nm_kf, _off = kf_runner.match_keyframes(kf_result)
+        barrier()
+        ap_s = time.perf_counter() - t1
+        ta = torch.tensor([ap_s], dtype=torch.float64, device=dev)
+        kn = kf_result.kf_n.to(torch.float64)
+        tot, sq2 = kn.sum().reshape(1), (kn ** 2).sum().reshape(1)
+        k_all = torch.tensor([float(kn.numel())], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot)
+            dist.all_reduce(sq2)
+            dist.all_reduce(k_all)
+        dpairs = float(tot.item()) ** 2 - float(sq2.item())
+        sequence = {"frames": n_seq, "batch": B, "keyframe_every": 10, "keyframes_total": int(k_all.item()),
+                    "sharding": f"contiguous blocks over {world} rank(s), one halo frame per block boundary",
+                    **legs,
+                    "pcie_over_resident": round(legs["pcie_inclusive"]["frames_per_s"] / legs["hbm_resident"]["frames_per_s"], 3),
+                    "keyframe_allpairs": {"seconds": round(float(ta.item()), 4), "descriptor_pairs": dpairs,
+                                          "descriptor_pairs_per_s": round(dpairs / float(ta.item()), 1),
+                                          "matches_rank0": int(nm_kf.sum().item()),
+                                          "exchange": "all_gather_into_tensor of descriptors + float angles (36 B per keypoint)"
+                                                      if world > 1 else "none (1 rank)"},
+                    "end_to_end_seconds": round(legs["pcie_inclusive"]["seconds"] + float(ta.item()), 4),
+                    "links_mean_rank0": round(float(kf_result.n_links.mean()), 1),
+                    "keypoints_mean_rank0": round(float(kf_result.n_keypoints.mean()), 1)}
+        del kf_result, nm_kf, pooled
+        torch.cuda.empty_cache()
 
     if rank != 0:
         if world > 1:
@@ -573,7 +642,7 @@ def main():
         projection = projection_bench(lib, fe.handle, g, d_kp, d_desc, n_kp, B, cap, W, H, dev, per_call=True)
 
     host_path = {}
-    if args.host_path and world == 1:
+    if not args.no_host_path and world == 1:
         # the boundary the reference's caller uses: host images in, host keypoints / descriptors out (orbgpu_extract_batch),
         # PCIe transfers and host staging included -- informational, never part of `value`
         ptrs = (C.c_void_p * B)(*[frames[i].ctypes.data for i in range(B)])
@@ -592,8 +661,29 @@ def main():
             t1 = time.perf_counter()
             check(lib.orbgpu_extract_batch(fe.handle, ptrs, 1, W, NF, _lib.ptr(h_kp), _lib.ptr(h_desc), cap, _lib.ptr(h_n)))
             one.append(time.perf_counter() - t1)
+        # one search by projection as SNNMatcher<ProjectionSearchIterator> makes it (monocular_frame.cpp:285-306): host
+        # arrays in, host results out, frame 0's keypoints searched among frame 1's (radius 15 x scale, TH 100, ratio 0.9)
+        n0, n1 = int(h_n[0]), int(h_n[1]) if B > 1 else int(h_n[0])
+        f1 = 1 if B > 1 else 0
+        k0, k1 = h_kp[0, :n0], h_kp[f1, :n1]
+        sc = np.array([g.scale[i] for i in range(g.levels)])
+        w_xy, w_from_xy = np.stack([k0["x"], k0["y"]], 1).copy(), np.stack([k1["x"], k1["y"]], 1).copy()
+        w_win = (15.0 * sc[k0["level"]]).astype(np.uint64)
+        w_lmin, w_lmax = np.maximum(k0["level"] - 1, 0).astype(np.int32), (k0["level"] + 1).astype(np.int32)
+        w_flv = k1["level"].astype(np.int32).copy()
+        w_td, w_fd = h_desc[0, :n0].copy(), h_desc[f1, :n1].copy()
+        wa = _lib.WindowArgs(_lib.ptr(w_td), _lib.ptr(w_xy), _lib.ptr(w_win), _lib.ptr(w_lmin), _lib.ptr(w_lmax), None, n0,
+                             _lib.ptr(w_fd), _lib.ptr(w_from_xy), _lib.ptr(w_flv), n1, 100, 0.9)
+        w_idx, w_dist = np.zeros(n0, np.int32), np.zeros(n0, np.uint32)
+        wt = []
+        for it in range(24):
+            t1 = time.perf_counter()
+            check(lib.orbgpu_match_window(fe.handle, C.byref(wa), _lib.ptr(w_idx), _lib.ptr(w_dist)))
+            wt.append(time.perf_counter() - t1)
         host_path = {"frames_per_s": round(B / hp, 1), "ms_per_batch": round(hp * 1e3, 3),
                      "single_frame_call_ms": round(float(np.median(one[2:])) * 1e3, 4),
+                     "single_window_search_ms": round(float(np.median(wt[4:])) * 1e3, 4),
+                     "single_window_search": f"{n0} x {n1} keypoints, host to host, {int((w_idx >= 0).sum())} matches",
                      "bytes_in_per_frame": W * H, "bytes_out_per_frame_mean": int(round(float(h_n.mean()) * 64)),
                      "includes": "host row copies into pinned memory (8 threads for a batch), H2D, extraction, D2H of keypoints and descriptors; synchronous call"}
 
@@ -674,6 +764,7 @@ def main():
                       "link_matches_mean": round(float(n_matches.mean()), 1) if n_pairs else 0.0,
                       "parallelism": f"frame-sharded x{world}"},
            "roofline": roofline, "pipeline": pipeline, "matching": matching, "keyframe_allpairs": allpairs,
+           "sequence": sequence,
            "keyframe_database": database, "host_pointer_path": host_path, "large_images": large,
            "projection_match": projection,
            "cpu_baseline": cpu}

@@ -90,6 +90,11 @@ int orbgpu_get_geometry(const orbgpu_ctx *ctx, int32_t feature_count, orbgpu_geo
  * synchronisation of that stream before a *_device call and orbgpu_synchronize before reading the results. */
 void *orbgpu_stream(orbgpu_ctx *ctx);
 int orbgpu_synchronize(orbgpu_ctx *ctx);
+/* No counterpart in the reference.  Waits for the context's work (like orbgpu_synchronize, whose status it returns) and
+ * releases the side streams an extract call forks onto (level 0's FAST launch, the blur, batch slices) together with
+ * their events; the next extract call re-creates the ones it needs.  A process maps all its streams onto 4 hardware
+ * queues: a caller that keeps several contexts alive but extracts with one at a time trims the idle ones. */
+int orbgpu_trim(orbgpu_ctx *ctx);
 /* Ordering against the caller's streams without a device-wide synchronisation (no counterpart in the reference, which
  * never leaves the CPU).  Either
  *  - orbgpu_set_stream: the context enqueues on the caller's stream (a hipStream_t; NULL = back to its own stream)
@@ -311,6 +316,16 @@ int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_ro
                                  const uint8_t *d_desc_cols, const int32_t *d_n_cols, int32_t n_cols, int32_t capacity,
                                  int32_t row_offset, uint32_t threshold, double ratio, int32_t check_orientation,
                                  int32_t *d_n_matches, int32_t *d_match);
+
+/* Same matcher (same reference counterpart: second_nearest_neighbor_matcher.hpp:30-80 + orientation_validator.cpp:16-97)
+ * for keyframe sets that travelled between GPUs: the rotation filter reads nothing of a keypoint but its angle, so the
+ * sharded workload all-gathers descriptors + a float side array (4 B per keypoint) instead of the 32-byte
+ * records.  d_angle_rows / d_angle_cols are [n][capacity] floats = KeyPoint::angle as orbgpu_keypoint holds it. */
+int orbgpu_match_allpairs_angles_device(orbgpu_ctx *ctx, const float *d_angle_rows, const uint8_t *d_desc_rows,
+                                        const int32_t *d_n_rows, int32_t n_rows, const float *d_angle_cols,
+                                        const uint8_t *d_desc_cols, const int32_t *d_n_cols, int32_t n_cols,
+                                        int32_t capacity, int32_t row_offset, uint32_t threshold, double ratio,
+                                        int32_t check_orientation, int32_t *d_n_matches, int32_t *d_match);
 
 /* replaces: OrientationValidator::Validate (validators/orientation_validator.cpp:16-97).
  * match[i] >= 0 means 'to' i is matched to 'from' match[i]; discarded matches are set to -1. */

@@ -68,12 +68,12 @@ assert KP_DTYPE.itemsize == 32
 
 # every symbol include/orbgpu.h declares (the inline orbgpu_hamming256 aside)
 EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_geometry", "orbgpu_stream",
-           "orbgpu_synchronize", "orbgpu_set_stream", "orbgpu_set_batch_slices", "orbgpu_wait_event", "orbgpu_record_event", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
+           "orbgpu_synchronize", "orbgpu_trim", "orbgpu_set_stream", "orbgpu_set_batch_slices", "orbgpu_wait_event", "orbgpu_record_event", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
            "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_bruteforce_noalloc_device", "orbgpu_set_bruteforce_engine",
            "orbgpu_match_window",
            "orbgpu_match_window_device", "orbgpu_match_window_segments_device", "orbgpu_grid_build_device",
            "orbgpu_match_window_grid_segments_device", "orbgpu_match_frames_device", "orbgpu_match_groups", "orbgpu_match_groups_device",
-           "orbgpu_match_allpairs_device", "orbgpu_vocab_create", "orbgpu_vocab_destroy", "orbgpu_bow_transform",
+           "orbgpu_match_allpairs_device", "orbgpu_match_allpairs_angles_device", "orbgpu_vocab_create", "orbgpu_vocab_destroy", "orbgpu_bow_transform",
            "orbgpu_bow_transform_device", "orbgpu_distinctive_descriptor", "orbgpu_distinctive_descriptor_device",
            "orbgpu_keypoint_geometry", "orbgpu_keypoint_geometry_device", "orbgpu_bow_score", "orbgpu_bow_score_device",
            "orbgpu_bowdb_create", "orbgpu_bowdb_destroy", "orbgpu_bowdb_append", "orbgpu_bowdb_erase", "orbgpu_bowdb_size",
@@ -103,6 +103,7 @@ def load():
         "orbgpu_get_geometry": (i32, [vp, i32, C.POINTER(Geometry)]),
         "orbgpu_stream": (vp, [vp]),
         "orbgpu_synchronize": (i32, [vp]),
+        "orbgpu_trim": (i32, [vp]),
         "orbgpu_set_stream": (i32, [vp, vp]),
         "orbgpu_set_batch_slices": (i32, [vp, i32]),
         "orbgpu_wait_event": (i32, [vp, vp]),
@@ -124,6 +125,7 @@ def load():
         "orbgpu_match_groups": (i32, [vp, C.POINTER(GroupArgs), vp, vp]),
         "orbgpu_match_groups_device": (i32, [vp, C.POINTER(GroupArgs), i32, vp, vp]),
         "orbgpu_match_allpairs_device": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, u32, dbl, i32, vp, vp]),
+        "orbgpu_match_allpairs_angles_device": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, u32, dbl, i32, vp, vp]),
         "orbgpu_distinctive_descriptor": (i32, [vp, vp, vp, i32, vp]),
         "orbgpu_distinctive_descriptor_device": (i32, [vp, vp, vp, i32, vp]),
         "orbgpu_keypoint_geometry": (i32, [vp, C.POINTER(Camera), vp, i32, vp, vp, vp]),

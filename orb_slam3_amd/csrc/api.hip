@@ -193,6 +193,36 @@ int keypoint_capacity(const orbgpu_ctx *ctx, int feature_count) {
   return cap;
 }
 
+// Side streams and fork / join events of slice s, created on first use: a default context (one slice) then holds three
+// streams (its own, level 0's FAST launch, the blur) instead of twelve -- a process has 4 hardware queues to map them on
+int ensure_slice(orbgpu_ctx *ctx, int s) {
+  if (s > 0 && !ctx->slice_stream[s]) HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_stream[s], hipStreamNonBlocking));
+  if (!ctx->slice_l0[s]) HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_l0[s], hipStreamNonBlocking));
+  if (!ctx->slice_blur[s]) HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_blur[s], hipStreamNonBlocking));
+  for (auto &e : ctx->slice_ev[s])
+    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return 0;
+}
+
+// drains and destroys every side stream and its events (they come back on demand)
+void release_side_streams(orbgpu_ctx *ctx) {
+  for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
+    hipStream_t *st[3] = {&ctx->slice_stream[k], &ctx->slice_blur[k], &ctx->slice_l0[k]};
+    for (hipStream_t *q : st)
+      if (*q) (void)hipStreamSynchronize(*q);
+    for (auto &e : ctx->slice_ev[k])
+      if (e) {
+        (void)hipEventDestroy(e);
+        e = nullptr;
+      }
+    for (hipStream_t *q : st)
+      if (*q) {
+        (void)hipStreamDestroy(*q);
+        *q = nullptr;
+      }
+  }
+}
+
 float elapsed(hipEvent_t a, hipEvent_t b) {
   float ms = 0;
   (void)hipEventElapsedTime(&ms, a, b);
@@ -219,6 +249,10 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   n_slices = std::max(1, std::min(std::min(n_slices, (int)orbgpu_ctx::MAX_SLICES), n_frames));
   // an event between two kernels of a stream costs 6-7 us of stream time: by default only the FAST kernel is bracketed
   const bool ends = ctx->stage_timing || n_slices > 1;  // ev[0]: start of the call (and the slices' fork), ev[9]: its end
+  for (int s = 0; s < n_slices; s++) {
+    const int rc = ensure_slice(ctx, s);
+    if (rc) return rc;
+  }
   if (ends) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
   for (int s = 0; s < n_slices; s++) {
     const int f0 = (int)((long long)n_frames * s / n_slices), f1 = (int)((long long)n_frames * (s + 1) / n_slices);
@@ -255,8 +289,12 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
       fork_ev = sev[0];
       HIP_TRY(hipEventRecord(sev[0], fs.stream));
     }
-    if (launch_quadtree(ctx, fs, budget) != 0)
+    if (launch_quadtree(ctx, fs, budget) != 0) {
+      // earlier slices joined the context's stream at the end of their turn and this slice's level-0 stream has joined
+      // fs.stream; a forked fs.stream itself has not: join it, so that the context's stream still covers all enqueued work
+      if (s > 0 && hipEventRecord(sev[2], fs.stream) == hipSuccess) (void)hipStreamWaitEvent(ctx->stream, sev[2], 0);
       return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
+    }
     if (timed) HIP_TRY(hipEventRecord(ev[4], fs.stream));
     launch_orient(ctx, fs);  // IC_Angle needs the unblurred levels only: beside the blur, behind the quadtree
     if (timed) HIP_TRY(hipEventRecord(ev[3], fs.stream));
@@ -293,10 +331,12 @@ int finish_pipeline(orbgpu_ctx *ctx) {
     const int n = ctx->ev_pending;
     ctx->ev_pending = 0;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int n_full = 0;  // sets that hold every stage boundary (orbgpu_set_stage_timing may have been toggled in between)
     for (int k = 1; k <= n; k++) {
       hipEvent_t *ev = ctx->ev[(ctx->ev_head - k + ORBGPU_EV_SETS) % ORBGPU_EV_SETS];
       acc[1] += elapsed(ev[1], ev[2]);  // FAST score + cells
       if (ctx->ev_full[(ctx->ev_head - k + ORBGPU_EV_SETS) % ORBGPU_EV_SETS]) {
+        n_full++;
         acc[0] += elapsed(ev[0], ev[1]);
         acc[6] += elapsed(ev[0], ev[9]);
         acc[2] += elapsed(ev[4], ev[3]);  // orientation, behind the quadtree and beside the blur
@@ -306,7 +346,7 @@ int finish_pipeline(orbgpu_ctx *ctx) {
         if (ctx->early_l0) acc[7] += elapsed(ev[10], ev[11]);  // FAST of level 0, on the second stream beside the pyramid
       }
     }
-    for (int i = 0; i < 8; i++) ctx->stage_ms[i] = acc[i] / (float)n;
+    for (int i = 0; i < 8; i++) ctx->stage_ms[i] = i == 1 ? acc[i] / (float)n : (n_full ? acc[i] / (float)n_full : 0.f);
   }
   if (*(volatile int *)ctx->h_error_flag != 0) {  // written by the kernels themselves (mapped host memory)
     const int code = *ctx->h_error_flag;
@@ -413,12 +453,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(match_noalloc_init(ctx->device));  // address of this GPU's copy of the fixed scratch array
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
-    for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
-      if (k > 0) HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_stream[k], hipStreamNonBlocking));
-      HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_l0[k], hipStreamNonBlocking));
-      HIP_TRY(hipStreamCreateWithFlags(&ctx->slice_blur[k], hipStreamNonBlocking));
-      for (auto &e : ctx->slice_ev[k]) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    // slice / level-0 / blur streams and their events are created by the first extract call that needs them (ensure_slice)
     for (auto &set : ctx->ev)
       for (auto &ev : set) HIP_TRY(hipEventCreate(&ev));
     HIP_TRY(dmalloc(&ctx->d_pyr, B * g.frame_bytes + 256));
@@ -575,18 +610,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   for (auto &set : ctx->ev)
     for (auto &ev : set)
       if (ev) (void)hipEventDestroy(ev);
-  for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
-    if (ctx->slice_stream[k]) (void)hipStreamSynchronize(ctx->slice_stream[k]);
-    if (ctx->slice_blur[k]) (void)hipStreamSynchronize(ctx->slice_blur[k]);
-    if (ctx->slice_l0[k]) (void)hipStreamSynchronize(ctx->slice_l0[k]);
-  }
-  for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
-    for (auto &e : ctx->slice_ev[k])
-      if (e) (void)hipEventDestroy(e);
-    if (ctx->slice_stream[k]) (void)hipStreamDestroy(ctx->slice_stream[k]);
-    if (ctx->slice_blur[k]) (void)hipStreamDestroy(ctx->slice_blur[k]);
-    if (ctx->slice_l0[k]) (void)hipStreamDestroy(ctx->slice_l0[k]);
-  }
+  release_side_streams(ctx);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -658,6 +682,15 @@ int orbgpu_synchronize(orbgpu_ctx *ctx) {
   if (!ctx) return ORBGPU_E_INVALID;
   std::lock_guard<std::mutex> lock(ctx->mu);
   return finish_pipeline(ctx);
+}
+
+int orbgpu_trim(orbgpu_ctx *ctx) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int rc = finish_pipeline(ctx);
+  release_side_streams(ctx);
+  return rc;
 }
 
 int orbgpu_extract_batch_device(orbgpu_ctx *ctx, const uint8_t *d_imgs, int64_t frame_stride, int32_t stride,
@@ -1633,6 +1666,27 @@ int orbgpu_bowdb_query(orbgpu_bowdb *db, const uint32_t *q_words, const double *
   return ORBGPU_OK;
 }
 
+static int match_allpairs_locked(orbgpu_ctx *ctx, const void *d_ang_rows, const uint8_t *d_desc_rows, const int32_t *d_n_rows,
+                                 int32_t n_rows, const void *d_ang_cols, int ang_stride, const uint8_t *d_desc_cols,
+                                 const int32_t *d_n_cols, int32_t n_cols, int32_t capacity, int32_t row_offset,
+                                 uint32_t threshold, double ratio, int32_t check_orientation, int32_t *d_n_matches,
+                                 int32_t *d_match) {
+  if (n_rows < 0 || n_cols < 0 || capacity < 1) return fail(ctx, ORBGPU_E_INVALID, "bad size");
+  if (n_rows == 0 || n_cols == 0) return ORBGPU_OK;
+  if (!d_desc_rows || !d_n_rows || !d_desc_cols || !d_n_cols || !d_n_matches) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  if (check_orientation && (!d_ang_rows || !d_ang_cols))
+    return fail(ctx, ORBGPU_E_INVALID, "check_orientation needs the keypoint (or angle) arrays of both sets");
+  // dynamic LDS plus the kernel's static __shared__ (rotation histogram, counters: < 256 B) must fit the 64 KB a
+  // workgroup gets without raising the limit
+  if (allpairs_lds_bytes(capacity) + 256 > 64 * 1024) return fail(ctx, ORBGPU_E_CAPACITY, "capacity above 4080 keypoints per keyframe");
+  if ((uint64_t)n_cols * (uint64_t)((n_rows + 7) & ~7) >= (1ull << 31)) return fail(ctx, ORBGPU_E_INVALID, "too many pairs for one call");
+  HIP_TRY(hipSetDevice(ctx->device));
+  launch_match_allpairs(ctx, d_ang_rows, d_desc_rows, d_n_rows, n_rows, d_ang_cols, ang_stride, d_desc_cols, d_n_cols, n_cols,
+                        capacity, row_offset, threshold, ratio, check_orientation, d_n_matches, d_match);
+  HIP_TRY(hipGetLastError());
+  return ORBGPU_OK;
+}
+
 int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
                                  const int32_t *d_n_rows, int32_t n_rows, const orbgpu_keypoint *d_kp_cols,
                                  const uint8_t *d_desc_cols, const int32_t *d_n_cols, int32_t n_cols, int32_t capacity,
@@ -1640,20 +1694,21 @@ int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_ro
                                  int32_t *d_n_matches, int32_t *d_match) {
   if (!ctx) return ORBGPU_E_INVALID;
   std::lock_guard<std::mutex> lock(ctx->mu);
-  if (n_rows < 0 || n_cols < 0 || capacity < 1) return fail(ctx, ORBGPU_E_INVALID, "bad size");
-  if (n_rows == 0 || n_cols == 0) return ORBGPU_OK;
-  if (!d_desc_rows || !d_n_rows || !d_desc_cols || !d_n_cols || !d_n_matches) return fail(ctx, ORBGPU_E_INVALID, "null argument");
-  if (check_orientation && (!d_kp_rows || !d_kp_cols))
-    return fail(ctx, ORBGPU_E_INVALID, "check_orientation needs the keypoint arrays of both sets");
-  // dynamic LDS plus the kernel's static __shared__ (rotation histogram, counters: < 256 B) must fit the 64 KB a
-  // workgroup gets without raising the limit
-  if (allpairs_lds_bytes(capacity) + 256 > 64 * 1024) return fail(ctx, ORBGPU_E_CAPACITY, "capacity above 4080 keypoints per keyframe");
-  if ((uint64_t)n_cols * (uint64_t)((n_rows + 7) & ~7) >= (1ull << 31)) return fail(ctx, ORBGPU_E_INVALID, "too many pairs for one call");
-  HIP_TRY(hipSetDevice(ctx->device));
-  launch_match_allpairs(ctx, d_kp_rows, d_desc_rows, d_n_rows, n_rows, d_kp_cols, d_desc_cols, d_n_cols, n_cols, capacity,
-                        row_offset, threshold, ratio, check_orientation, d_n_matches, d_match);
-  HIP_TRY(hipGetLastError());
-  return ORBGPU_OK;
+  return match_allpairs_locked(ctx, d_kp_rows ? &d_kp_rows->angle : nullptr, d_desc_rows, d_n_rows, n_rows,
+                               d_kp_cols ? &d_kp_cols->angle : nullptr, (int)sizeof(orbgpu_keypoint), d_desc_cols, d_n_cols,
+                               n_cols, capacity, row_offset, threshold, ratio, check_orientation, d_n_matches, d_match);
+}
+
+int orbgpu_match_allpairs_angles_device(orbgpu_ctx *ctx, const float *d_angle_rows, const uint8_t *d_desc_rows,
+                                        const int32_t *d_n_rows, int32_t n_rows, const float *d_angle_cols,
+                                        const uint8_t *d_desc_cols, const int32_t *d_n_cols, int32_t n_cols,
+                                        int32_t capacity, int32_t row_offset, uint32_t threshold, double ratio,
+                                        int32_t check_orientation, int32_t *d_n_matches, int32_t *d_match) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  return match_allpairs_locked(ctx, d_angle_rows, d_desc_rows, d_n_rows, n_rows, d_angle_cols, (int)sizeof(float), d_desc_cols,
+                               d_n_cols, n_cols, capacity, row_offset, threshold, ratio, check_orientation, d_n_matches,
+                               d_match);
 }
 
 int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to, const float *angle_from, int32_t n_from,

@@ -1246,9 +1246,12 @@ __global__ __launch_bounds__(256) void k_distinctive(const uint8_t *__restrict__
 // Work order: XCD k takes rows k, k+8, ... and walks their columns, so a row's descriptors stay in that XCD's L2.
 constexpr int AP_T = 4;
 
-__global__ __launch_bounds__(256) void k_allpairs(const orbgpu_keypoint *__restrict__ kp_rows,
+// The rotation histogram reads one float per keypoint: ang_rows / ang_cols point at the angle of keypoint 0 of
+// keyframe 0 and ang_stride is the distance in bytes between consecutive keypoints' angles (32 for orbgpu_keypoint
+// records, 4 for a plain float side array -- what crosses xGMI in the sharded workload).
+__global__ __launch_bounds__(256) void k_allpairs(const char *__restrict__ ang_rows,
                                                   const uint8_t *__restrict__ desc_rows, const int *__restrict__ n_rows_kp,
-                                                  int n_rows, const orbgpu_keypoint *__restrict__ kp_cols,
+                                                  int n_rows, const char *__restrict__ ang_cols, int ang_stride,
                                                   const uint8_t *__restrict__ desc_cols, const int *__restrict__ n_cols_kp,
                                                   int n_cols, int capacity, int row_offset, unsigned threshold,
                                                   double ratio, int check_orientation, int *__restrict__ n_matches,
@@ -1344,9 +1347,10 @@ __global__ __launch_bounds__(256) void k_allpairs(const orbgpu_keypoint *__restr
   if (cnt) atomicAdd(&total, cnt);
   __syncthreads();
   if (check_orientation) {
-    const orbgpu_keypoint *kt = kp_rows + (size_t)r * capacity, *kf = kp_cols + (size_t)c * capacity;
+    const char *kt = ang_rows + (size_t)r * capacity * ang_stride, *kf = ang_cols + (size_t)c * capacity * ang_stride;
     rotation_filter_block(
-        n_to, mj, [&](int i) { return kt[i].angle; }, [&](int jj) { return kf[jj].angle; }, nullptr, out_n);
+        n_to, mj, [&](int i) { return *reinterpret_cast<const float *>(kt + (size_t)i * ang_stride); },
+        [&](int jj) { return *reinterpret_cast<const float *>(kf + (size_t)jj * ang_stride); }, nullptr, out_n);
     __syncthreads();
   } else if (threadIdx.x == 0) {
     *out_n = total;
@@ -1684,15 +1688,16 @@ void launch_distinctive(const orbgpu_ctx *c, const uint8_t *d_desc, const int *d
 
 size_t allpairs_lds_bytes(int capacity) { return (size_t)capacity * 16; }
 
-void launch_match_allpairs(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
-                           const int *d_n_rows, int n_rows, const orbgpu_keypoint *d_kp_cols, const uint8_t *d_desc_cols,
+void launch_match_allpairs(const orbgpu_ctx *c, const void *d_ang_rows, const uint8_t *d_desc_rows, const int *d_n_rows,
+                           int n_rows, const void *d_ang_cols, int ang_stride, const uint8_t *d_desc_cols,
                            const int *d_n_cols, int n_cols, int capacity, int row_offset, unsigned threshold, double ratio,
                            int check_orientation, int *d_n_matches, int *d_match) {
   const unsigned th = std::min(threshold, 256u);
   dim3 grid((unsigned)n_cols * (unsigned)xcd_frames(n_rows));
-  hipLaunchKernelGGL(k_allpairs, grid, dim3(256), allpairs_lds_bytes(capacity), c->stream, d_kp_rows, d_desc_rows, d_n_rows,
-                     n_rows, d_kp_cols, d_desc_cols, d_n_cols, n_cols, capacity, row_offset, th, ratio, check_orientation,
-                     d_n_matches, d_match);
+  hipLaunchKernelGGL(k_allpairs, grid, dim3(256), allpairs_lds_bytes(capacity), c->stream,
+                     reinterpret_cast<const char *>(d_ang_rows), d_desc_rows, d_n_rows, n_rows,
+                     reinterpret_cast<const char *>(d_ang_cols), ang_stride, d_desc_cols, d_n_cols, n_cols, capacity,
+                     row_offset, th, ratio, check_orientation, d_n_matches, d_match);
 }
 
 void launch_rotation_filter(const orbgpu_ctx *c, const float *d_ang_to, int n_to, const float *d_ang_from, int *d_match,

@@ -301,8 +301,9 @@ void launch_bowdb_compact(const orbgpu_ctx *c, int n_keyframes, const long long 
                           unsigned *w_out, double *v_out, unsigned *c_out);
 void launch_distinctive(const orbgpu_ctx *c, const uint8_t *d_desc, const int *d_offsets, int n_points, int *d_best);
 size_t allpairs_lds_bytes(int capacity);
-void launch_match_allpairs(const orbgpu_ctx *c, const orbgpu_keypoint *d_kp_rows, const uint8_t *d_desc_rows,
-                           const int *d_n_rows, int n_rows, const orbgpu_keypoint *d_kp_cols, const uint8_t *d_desc_cols,
+// d_ang_rows / d_ang_cols: the angle (float) of keypoint 0 of keyframe 0; ang_stride: bytes between two keypoints' angles
+void launch_match_allpairs(const orbgpu_ctx *c, const void *d_ang_rows, const uint8_t *d_desc_rows, const int *d_n_rows,
+                           int n_rows, const void *d_ang_cols, int ang_stride, const uint8_t *d_desc_cols,
                            const int *d_n_cols, int n_cols, int capacity, int row_offset, unsigned threshold, double ratio,
                            int check_orientation, int *d_n_matches, int *d_match);
 void launch_rotation_filter(const orbgpu_ctx *c, const float *d_ang_to, int n_to, const float *d_ang_from, int *d_match,

@@ -84,6 +84,28 @@ def frame(seed, h=480, w=640):
     return world(seed, h, w)
 
 
+class ProceduralSequence:
+    """Frame `i` of an arbitrarily long 'TUM-shaped' sequence as a pure function of (seed, i): one seeded scene and a
+    closed-form camera path (slow sinusoids: <= 2.2 px and <= 0.2 deg between consecutive frames), so any rank can produce
+    any frame of its block without the frames before it and no dataset moves (SURVEY 8d input 5)."""
+
+    def __init__(self, seed, h=480, w=640, margin=96):
+        self.seed, self.h, self.w, self.margin = int(seed), int(h), int(w), int(margin)
+        self.scene = world(self.seed + 7919, self.h + 2 * margin, self.w + 2 * margin)
+        rng = np.random.default_rng(self.seed)
+        self.phase = rng.uniform(0, 2 * np.pi, 3)
+
+    def pose(self, i):
+        a = self.margin * 0.45
+        tx = a * np.sin(0.047 * i + self.phase[0])
+        ty = a * np.sin(0.031 * i + self.phase[1])
+        rot = 7.0 * np.sin(0.027 * i + self.phase[2])
+        return float(tx), float(ty), float(rot)
+
+    def frame(self, i):
+        return _warp(self.scene, self.h, self.w, *self.pose(int(i)))
+
+
 def descriptors(seed, n, planted_from=None, planted_frac=0.3, max_flips=40):
     """n x 32 uniform random descriptors; optionally a fraction are noisy copies of rows of `planted_from`."""
     rng = np.random.default_rng(seed)
