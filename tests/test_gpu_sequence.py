@@ -100,17 +100,21 @@ def test_sequence_equals_one_batch_calls(runner, full_run):
                                           d_nm.data_ptr()) == 0
     assert lib.orbgpu_synchronize(fe.handle) == 0
     res = full_run
-    assert np.array_equal(d_n.cpu().numpy(), res.n_keypoints[a:b])
-    assert np.array_equal(d_kp.cpu().numpy().view(_lib.KP_DTYPE).reshape(n, cap), res.keypoints[a:b])
-    assert np.array_equal(d_desc.cpu().numpy(), res.descriptors[a:b])
-    assert np.array_equal(d_m.cpu().numpy(), res.links[a + 1:b])
+    cnt = d_n.cpu().numpy()
+    assert np.array_equal(cnt, res.n_keypoints[a:b])
+    kp, desc = d_kp.cpu().numpy().view(_lib.KP_DTYPE).reshape(n, cap), d_desc.cpu().numpy()
+    for f in range(n):                     # rows beyond a frame's count are not written by the extractor
+        same_kp = np.array_equal(kp[f, :cnt[f]], res.keypoints[a + f, :cnt[f]])
+        same_desc = np.array_equal(desc[f, :cnt[f]], res.descriptors[a + f, :cnt[f]])
+        assert same_kp and same_desc, f"frame {a + f}"
+    same_links = np.array_equal(d_m.cpu().numpy(), res.links[a + 1:b])
+    assert same_links
     assert np.array_equal(d_nm.cpu().numpy(), res.n_links[a + 1:b])
 
 
 def test_sequence_sharded_blocks_equal_single_run(runner, full_run):
-    """The same 600 frames as the blocks of 3 ranks (ragged: 200 each would be even, so 601 frames are cut 201 / 200 /
-    200 -- here 600 over 7 ranks: 86 / 86 / 86 / 86 / 86 / 85 / 85): every rank's owned frames, links (the first one
-    through its halo frame) and keyframes equal the single run's."""
+    """The same 600 frames as the blocks of 7 ranks (ragged: 86 / 86 / 86 / 86 / 86 / 85 / 85): every rank's owned frames,
+    links (the first one through its halo frame) and keyframes equal the single run's."""
     res = full_run
     world = 7
     kf_seen = []
@@ -120,14 +124,20 @@ def test_sequence_sharded_blocks_equal_single_run(runner, full_run):
         assert part.timing["frames_extracted"] == blk.n_owned + (1 if rank > 0 else 0)
         s, e = blk.start, blk.stop
         assert np.array_equal(part.n_keypoints, res.n_keypoints[s:e])
-        assert np.array_equal(part.keypoints, res.keypoints[s:e])
-        assert np.array_equal(part.descriptors, res.descriptors[s:e])
+        for f in range(s, e):
+            c = res.n_keypoints[f]
+            same_kp = np.array_equal(part.keypoints[f - s, :c], res.keypoints[f, :c])
+            same_desc = np.array_equal(part.descriptors[f - s, :c], res.descriptors[f, :c])
+            assert same_kp and same_desc, f"rank {rank} frame {f}"
         assert np.array_equal(part.n_links, res.n_links[s:e])          # includes the link through the halo frame
-        assert np.array_equal(part.links, res.links[s:e])
+        same_links = np.array_equal(part.links, res.links[s:e])
+        assert same_links, f"rank {rank}"
         kf_seen += part.keyframe_ids
         q0 = res.keyframe_ids.index(part.keyframe_ids[0])
-        assert np.array_equal(part.kf_n.cpu().numpy(), res.kf_n.cpu().numpy()[q0:q0 + len(part.keyframe_ids)])
-        assert np.array_equal(part.kf_desc.cpu().numpy(), res.kf_desc.cpu().numpy()[q0:q0 + len(part.keyframe_ids)])
+        pn, rn = part.kf_n.cpu().numpy(), res.kf_n.cpu().numpy()[q0:q0 + len(part.keyframe_ids)]
+        assert np.array_equal(pn, rn)
+        pd, rd = part.kf_desc.cpu().numpy(), res.kf_desc.cpu().numpy()[q0:q0 + len(part.keyframe_ids)]
+        assert all(np.array_equal(pd[q, :pn[q]], rd[q, :pn[q]]) for q in range(len(pn))), f"rank {rank} keyframes"
     assert kf_seen == res.keyframe_ids
 
 
@@ -166,9 +176,16 @@ def test_sequence_pooled_and_resident_sources(runner):
         r = SequenceRunner(fe, src, NF, keyframe_every=EVERY)
         out.append(r.run(300, keep_links=True, keep_features=True))
     a, b = out
-    assert np.array_equal(a.n_keypoints, b.n_keypoints) and np.array_equal(a.descriptors, b.descriptors)
-    assert np.array_equal(a.links, b.links) and np.array_equal(a.n_links, b.n_links)
+    assert np.array_equal(a.n_keypoints, b.n_keypoints) and np.array_equal(a.n_links, b.n_links)
+    for f in range(300):
+        c = a.n_keypoints[f]
+        same = np.array_equal(a.descriptors[f, :c], b.descriptors[f, :c]) and np.array_equal(a.links[f], b.links[f])
+        assert same, f"frame {f}"
     # frame i = pool frame i % 24: same keypoints whenever the pool index repeats; the link of frame 24 goes back to 23
-    assert np.array_equal(a.descriptors[3], a.descriptors[27]) and np.array_equal(a.descriptors[3], a.descriptors[3 + 24 * 11])
-    assert np.array_equal(a.links[5], a.links[29]) and a.n_links[5] > 100
+    c = a.n_keypoints[3]
+    assert a.n_keypoints[27] == c and a.n_keypoints[3 + 24 * 11] == c
+    same = np.array_equal(a.descriptors[3, :c], a.descriptors[27, :c]) and np.array_equal(a.descriptors[3, :c], a.descriptors[3 + 24 * 11, :c])
+    assert same
+    same = np.array_equal(a.links[5], a.links[29])
+    assert same and a.n_links[5] > 100
     assert a.timing["bytes_uploaded"] == 300 * W * H
