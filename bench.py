@@ -656,11 +656,20 @@ def main():
             times.append(time.perf_counter() - t1)
         hp = min(times[1:])
         # one frame per call, as IFeatureExtractor::Extract is called by the reference (feature_handler_factory.cpp:50)
+        # (a context of its own with max_batch = 1, as a per-frame caller creates it: the whole call is one captured graph)
+        fe1 = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, device=local_rank, max_batch=1, max_features=NF)
         one = []
-        for it in range(12):
+        k1_, d1_, n1_ = np.zeros(cap, _lib.KP_DTYPE), np.zeros((cap, 32), np.uint8), C.c_int32(0)
+        for it in range(40):
             t1 = time.perf_counter()
-            check(lib.orbgpu_extract_batch(fe.handle, ptrs, 1, W, NF, _lib.ptr(h_kp), _lib.ptr(h_desc), cap, _lib.ptr(h_n)))
+            rc1 = lib.orbgpu_extract(fe1.handle, frames[it % B].ctypes.data, W, H, W, NF, _lib.ptr(k1_), _lib.ptr(d1_), cap,
+                                     C.byref(n1_))
             one.append(time.perf_counter() - t1)
+            if rc1 != 0:
+                raise RuntimeError(lib.orbgpu_last_error(fe1.handle).decode())
+        same_one = bool(n1_.value == h_n[39 % B] and np.array_equal(d1_[:n1_.value], h_desc[39 % B, :n1_.value]))
+        assert same_one, "single-frame call differs from the batch call on the same frame"
+        fe1.close()
         # one search by projection as SNNMatcher<ProjectionSearchIterator> makes it (monocular_frame.cpp:285-306): host
         # arrays in, host results out, frame 0's keypoints searched among frame 1's (radius 15 x scale, TH 100, ratio 0.9)
         n0, n1 = int(h_n[0]), int(h_n[1]) if B > 1 else int(h_n[0])
@@ -681,7 +690,7 @@ def main():
             check(lib.orbgpu_match_window(fe.handle, C.byref(wa), _lib.ptr(w_idx), _lib.ptr(w_dist)))
             wt.append(time.perf_counter() - t1)
         host_path = {"frames_per_s": round(B / hp, 1), "ms_per_batch": round(hp * 1e3, 3),
-                     "single_frame_call_ms": round(float(np.median(one[2:])) * 1e3, 4),
+                     "single_frame_call_ms": round(float(np.median(one[8:])) * 1e3, 4),
                      "single_window_search_ms": round(float(np.median(wt[4:])) * 1e3, 4),
                      "single_window_search": f"{n0} x {n1} keypoints, host to host, {int((w_idx >= 0).sum())} matches",
                      "bytes_in_per_frame": W * H, "bytes_out_per_frame_mean": int(round(float(h_n.mean()) * 64)),

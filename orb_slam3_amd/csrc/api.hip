@@ -237,8 +237,9 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 // streams forked from it (and joined back into it at the end): every kernel here is bound by instruction issue or by
 // latency, never by HBM, so the dependent, latency-bound stages of one slice (quadtree rounds, orientation ->
 // descriptor chains, small pyramid levels) fill issue slots that the instruction-bound stages of another leave.
+// capture: the call is being recorded into a hipGraph (single-frame host path): no timing events, no event-ring bookkeeping
 int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
-                 int *d_n_out) {
+                 int *d_n_out, bool capture = false) {
   const DeviceGeom &g = ctx->geom;
   const int L = g.levels;
   int budget[ORBGPU_MAX_LEVELS];
@@ -248,7 +249,8 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   int n_slices = ctx->n_slices > 0 ? ctx->n_slices : 1;
   n_slices = std::max(1, std::min(std::min(n_slices, (int)orbgpu_ctx::MAX_SLICES), n_frames));
   // an event between two kernels of a stream costs 6-7 us of stream time: by default only the FAST kernel is bracketed
-  const bool ends = ctx->stage_timing || n_slices > 1;  // ev[0]: start of the call (and the slices' fork), ev[9]: its end
+  const bool stage_timing = ctx->stage_timing && !capture;
+  const bool ends = stage_timing || n_slices > 1;  // ev[0]: start of the call (and the slices' fork), ev[9]: its end
   for (int s = 0; s < n_slices; s++) {
     const int rc = ensure_slice(ctx, s);
     if (rc) return rc;
@@ -259,8 +261,8 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     const FrameSlice fs{f0, f1 - f0, s == 0 ? ctx->stream : ctx->slice_stream[s]};
     const FrameSlice fb{f0, f1 - f0, ctx->no_overlap ? fs.stream : ctx->slice_blur[s]};
     hipEvent_t *sev = ctx->slice_ev[s];
-    const bool timed = s == 0 && ctx->stage_timing;  // the stage timers follow slice 0
-    const bool timed_fast = s == 0;                  // the FAST kernel (the roofline kernel) is always bracketed
+    const bool timed = s == 0 && stage_timing;       // the stage timers follow slice 0
+    const bool timed_fast = s == 0 && !capture;      // the FAST kernel (the roofline kernel) is always bracketed
     if (s > 0) HIP_TRY(hipStreamWaitEvent(fs.stream, ev[0], 0));  // fork: after everything already on the context's stream
     const bool early = ctx->early_l0;
     if (early) {  // level 0 needs no pyramid: its FAST groups on a stream of their own, beside the resize chain
@@ -312,9 +314,13 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
       HIP_TRY(hipStreamWaitEvent(ctx->stream, sev[2], 0));
     }
   }
-  if (ctx->stage_timing) HIP_TRY(hipEventRecord(ev[9], ctx->stream));  // every slice has finished
+  if (stage_timing) HIP_TRY(hipEventRecord(ev[9], ctx->stream));  // every slice has finished
   HIP_TRY(hipGetLastError());
-  ctx->ev_full[ctx->ev_head] = ctx->stage_timing;
+  ctx->last_frames = n_frames;
+  ctx->last_feature_count = feature_count;
+  ctx->last_slices = n_slices;
+  if (capture) return 0;
+  ctx->ev_full[ctx->ev_head] = stage_timing;
   ctx->ev_head = (ctx->ev_head + 1) % ORBGPU_EV_SETS;
   ctx->ev_pending = std::min(ctx->ev_pending + 1, ORBGPU_EV_SETS);
   ctx->last_frames = n_frames;
@@ -365,28 +371,135 @@ int finish_pipeline(orbgpu_ctx *ctx) {
 }  // namespace
 
 namespace {
-// host-pointer wrappers stage through one temporary device allocation per call
+// Host-pointer wrappers stage through ONE persistent pair of buffers per context, grown on demand (no hipMalloc / hipFree
+// per call): pinned + mapped host memory and a device buffer of the same size.  put() packs an input array into the
+// host buffer and returns the address of its copy in the device buffer; upload() moves everything packed so far with one
+// host-to-device copy on the context's stream; regions put(nullptr, n) are outputs.  host_of() / mapped_of() give the
+// host twin of a region and the address under which kernels can write that twin directly (small results: no copy back).
+// Valid only while the caller holds the context's mutex from reserve() to its last use of the buffers.
+int ensure_stage(orbgpu_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->stage_bytes) return 0;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_stage) HIP_TRY(hipHostFree(ctx->h_stage));
+  if (ctx->d_stage) HIP_TRY(hipFree(ctx->d_stage));
+  ctx->h_stage = ctx->h_stage_dev = ctx->d_stage = nullptr;
+  ctx->stage_bytes = 0;
+  bytes = std::max<size_t>((bytes + (bytes >> 2) + (1u << 20)) & ~(size_t)((1u << 20) - 1), 1u << 20);
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage), bytes, hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_stage_dev), ctx->h_stage, 0));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stage), bytes));
+  ctx->stage_bytes = bytes;
+  return 0;
+}
+
 struct Staging {
   orbgpu_ctx *ctx;
-  char *base = nullptr;
-  size_t used = 0, cap = 0;
-  ~Staging() {
-    if (base) (void)hipFree(base);
-  }
-  int reserve(size_t bytes) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), bytes + 4096));
-    cap = bytes + 4096;
-    return 0;
-  }
+  size_t used = 0, in_end = 0;
+  int reserve(size_t bytes) { return ensure_stage(ctx, bytes + 4096); }
   template <class T>
   T *put(const T *h, size_t n) {
     used = (used + 255) & ~(size_t)255;
-    T *d = reinterpret_cast<T *>(base + used);
+    T *d = reinterpret_cast<T *>(ctx->d_stage + used);
+    if (h && n) {
+      std::memcpy(ctx->h_stage + used, h, n * sizeof(T));
+      in_end = used + n * sizeof(T);
+    }
     used += n * sizeof(T);
-    if (h && n) (void)hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
     return d;
   }
+  hipError_t upload() {
+    return in_end ? hipMemcpyAsync(ctx->d_stage, ctx->h_stage, in_end, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+  }
+  template <class T>
+  T *host_of(T *d) const { return reinterpret_cast<T *>(ctx->h_stage + (reinterpret_cast<char *>(d) - ctx->d_stage)); }
+  template <class T>
+  T *mapped_of(T *d) const { return reinterpret_cast<T *>(ctx->h_stage_dev + (reinterpret_cast<char *>(d) - ctx->d_stage)); }
+  // device -> the region's host twin (a pinned copy), enqueued; the caller synchronises and then copies out with fetch()
+  template <class T>
+  hipError_t download(T *d, size_t n) {
+    return n ? hipMemcpyAsync(host_of(d), d, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+  }
+  template <class T>
+  void fetch(T *dst, T *d, size_t n) const {
+    if (n) std::memcpy(dst, host_of(d), n * sizeof(T));
+  }
 };
+}  // namespace
+
+namespace {
+// One frame per call, host to host -- how the reference calls Extract (factories/feature_handler_factory.cpp:50).  The eager
+// pipeline costs the host ~100 us of launches and event calls for ~17 short dependent kernels, then three small copies
+// back; here the whole call (upload of the staged image, every kernel with its forks and joins) is ONE captured hipGraph
+// per (feature_count), and the last kernel writes keypoints, descriptors and the count straight into mapped host memory:
+// per call one memcpy into pinned memory, one hipGraphLaunch, one stream wait, one memcpy out.
+int extract_one_frame_graph(orbgpu_ctx *ctx, const uint8_t *img, int stride, int feature_count, orbgpu_keypoint *kp,
+                            uint8_t *desc, int capacity, int32_t *n_out) {
+  const LevelGeom &L0 = ctx->geom.lv[0];
+  const int w = ctx->params.width, h = ctx->params.height, cap_dev = ctx->out_capacity;
+  const size_t kp_bytes = pad256((size_t)cap_dev * sizeof(orbgpu_keypoint)), desc_bytes = pad256((size_t)cap_dev * 32);
+  if (!ctx->h_one) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_one), kp_bytes + desc_bytes + 256, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->h_one_dev), ctx->h_one, 0));
+  }
+  orbgpu_keypoint *m_kp = reinterpret_cast<orbgpu_keypoint *>(ctx->h_one_dev);
+  uint8_t *m_desc = reinterpret_cast<uint8_t *>(ctx->h_one_dev + kp_bytes);
+  int *m_n = reinterpret_cast<int *>(ctx->h_one_dev + kp_bytes + desc_bytes);
+  uint8_t *dst = ctx->h_imgs;
+  if (stride == L0.pitch) {
+    std::memcpy(dst, img, (size_t)L0.pitch * (h - 1) + w);
+  } else {
+    for (int y = 0; y < h; y++) {
+      std::memcpy(dst + (size_t)y * L0.pitch, img + (size_t)y * stride, (size_t)w);
+      std::memset(dst + (size_t)y * L0.pitch + w, 0, (size_t)(L0.pitch - w));
+    }
+  }
+  auto upload = [&]() {
+    return hipMemcpyAsync(ctx->d_pyr + L0.off, dst, (size_t)L0.pitch * L0.h, hipMemcpyHostToDevice, ctx->stream);
+  };
+  ctx->lvl0 = Level0Src{nullptr, 0};
+  const int n_slices_saved = ctx->n_slices;
+  if (!ctx->graph_one || ctx->graph_one_features != feature_count) {
+    if (ctx->graph_one) {
+      (void)hipGraphExecDestroy(ctx->graph_one);
+      ctx->graph_one = nullptr;
+    }
+    // one eager pass first: it raises the kernels' LDS limits, sizes lazily created state and surfaces capacity errors
+    HIP_TRY(upload());
+    ctx->n_slices = 1;
+    int rc = run_pipeline(ctx, 1, feature_count, m_kp, m_desc, cap_dev, m_n);
+    ctx->n_slices = n_slices_saved;
+    if (rc) return rc;
+    rc = finish_pipeline(ctx);
+    if (rc) return rc;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    hipError_t e = upload();
+    ctx->n_slices = 1;
+    rc = e == hipSuccess ? run_pipeline(ctx, 1, feature_count, m_kp, m_desc, cap_dev, m_n, true) : 0;
+    ctx->n_slices = n_slices_saved;
+    const hipError_t e2 = hipStreamEndCapture(ctx->stream, &graph);  // always ends the capture, also after a failure
+    if (rc) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    HIP_TRY(e);
+    HIP_TRY(e2);
+    const hipError_t e3 = hipGraphInstantiate(&ctx->graph_one, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIP_TRY(e3);
+    ctx->graph_one_features = feature_count;
+  }
+  HIP_TRY(hipGraphLaunch(ctx->graph_one, ctx->stream));
+  int rc = finish_pipeline(ctx);
+  if (rc) return rc;
+  const int tot = *reinterpret_cast<volatile int *>(ctx->h_one + kp_bytes + desc_bytes);
+  if (tot > cap_dev) return fail(ctx, ORBGPU_E_CAPACITY, "internal keypoint capacity too small: need " + std::to_string(tot));
+  if (tot > capacity) return fail(ctx, ORBGPU_E_CAPACITY, "caller capacity too small: need " + std::to_string(tot));
+  n_out[0] = tot;
+  std::memcpy(kp, ctx->h_one, (size_t)tot * sizeof(orbgpu_keypoint));
+  std::memcpy(desc, ctx->h_one + kp_bytes, (size_t)tot * 32);
+  return ORBGPU_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -416,8 +529,11 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     ctx->window_plain_scan = ws && ws[0] == '1';
     const char *wg = std::getenv("ORBGPU_WINDOW_GRID_MIN");  // tuning / tests: smallest n_from that takes the grid
     if (wg) ctx->window_grid_min_from = std::max(1, std::atoi(wg));
+    ctx->window_grid_forced = wg != nullptr;
     const char *ls = std::getenv("ORBGPU_LINK_SCAN");  // 1: large-capacity frame links by the plain scan, not the grid
     ctx->link_plain_scan = ls && ls[0] == '1';
+    const char *ng = std::getenv("ORBGPU_NO_GRAPH");  // 1: single-frame host calls enqueue eagerly instead of replaying a hipGraph
+    ctx->graph_single_frame = !(ng && ng[0] == '1');
     const char *o = std::getenv("ORBGPU_SLICES");  // tuning aid: slices per batch, 0 / unset = automatic
     ctx->n_slices = o ? std::atoi(o) : 0;
   }
@@ -469,7 +585,9 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       const char *rk = std::getenv("ORBGPU_RESIZE");  // ORBGPU_RESIZE=tiles: the LDS-tiled kernel for every level
       const bool tiles = rk && std::string(rk) == "tiles";
       const char *rt = std::getenv("ORBGPU_RESIZE_STRIPS");  // tuning aid: strips per frame a level should reach
-      const int rs_target = rt ? std::atoi(rt) : 32;
+      // a one-frame context (max_batch == 1: the online call shape) is bound by the latency of the chain, not by
+      // throughput: short strips give a level's single frame enough waves (orbgpu_extract 179 -> 162 us host to host)
+      const int rs_target = rt ? std::atoi(rt) : (params->max_batch == 1 ? 256 : 32);
       for (int l = 1; l < g.levels; l++) {
         ctx->rs_strip_off[l] = (int)(rs.size() / 4);
         ctx->rs_items[l] = tiles ? 0 : build_resize_strips(g, l, xt.data() + g.lv[l].xtab_off, rs, rs_target);
@@ -494,7 +612,9 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
         }
       } else {
         const char *mp = std::getenv("ORBGPU_RESIZE_NEST_MAXPX");
-        const long long maxpx = mp ? std::atoll(mp) : 0;
+        // one-frame contexts nest every level they can (three launches instead of seven: 162 -> 143 us host to host);
+        // batches keep one launch per level (beside level 0's FAST groups the nests measured no gain)
+        const long long maxpx = mp ? std::atoll(mp) : (params->max_batch == 1 ? LLONG_MAX : 0);
         int s0 = g.levels;
         while (s0 > 1 && (long long)g.lv[s0 - 1].w * g.lv[s0 - 1].h < maxpx) s0--;
         int count = g.levels - s0;
@@ -604,7 +724,10 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
     if (n.d_xr) (void)hipFree(n.d_xr);
     if (n.d_yr) (void)hipFree(n.d_yr);
   }
-  void *hptrs[] = {ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag};
+  if (ctx->graph_one) (void)hipGraphExecDestroy(ctx->graph_one);
+  if (ctx->h_one) (void)hipHostFree(ctx->h_one);
+  if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+  void *hptrs[] = {ctx->h_kp_count, ctx->h_imgs, ctx->h_out, ctx->h_error_flag, ctx->h_stage};
   for (void *p : hptrs)
     if (p) (void)hipHostFree(p);
   for (auto &set : ctx->ev)
@@ -639,7 +762,7 @@ void *orbgpu_stream(orbgpu_ctx *ctx) { return ctx ? (void *)ctx->stream : nullpt
 
 int orbgpu_set_stream(orbgpu_ctx *ctx, void *stream) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
   // work already enqueued keeps its order: the old stream drains before the switch (this also collects its stage timers
   // and device-side errors)
@@ -650,21 +773,21 @@ int orbgpu_set_stream(orbgpu_ctx *ctx, void *stream) {
 
 int orbgpu_set_stage_timing(orbgpu_ctx *ctx, int32_t all_stages) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   ctx->stage_timing = all_stages != 0;
   return ORBGPU_OK;
 }
 
 int orbgpu_set_batch_slices(orbgpu_ctx *ctx, int32_t n_slices) {
   if (!ctx || n_slices < 0 || n_slices > orbgpu_ctx::MAX_SLICES) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   ctx->n_slices = n_slices;
   return ORBGPU_OK;
 }
 
 int orbgpu_wait_event(orbgpu_ctx *ctx, void *event) {
   if (!ctx || !event) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamWaitEvent(ctx->stream, static_cast<hipEvent_t>(event), 0));
   return ORBGPU_OK;
@@ -672,7 +795,7 @@ int orbgpu_wait_event(orbgpu_ctx *ctx, void *event) {
 
 int orbgpu_record_event(orbgpu_ctx *ctx, void *event) {
   if (!ctx || !event) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(event), ctx->stream));
   return ORBGPU_OK;
@@ -680,13 +803,13 @@ int orbgpu_record_event(orbgpu_ctx *ctx, void *event) {
 
 int orbgpu_synchronize(orbgpu_ctx *ctx) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   return finish_pipeline(ctx);
 }
 
 int orbgpu_trim(orbgpu_ctx *ctx) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
   const int rc = finish_pipeline(ctx);
   release_side_streams(ctx);
@@ -697,7 +820,7 @@ int orbgpu_extract_batch_device(orbgpu_ctx *ctx, const uint8_t *d_imgs, int64_t 
                                 int32_t n_frames, int32_t feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc,
                                 int32_t capacity, int32_t *d_n_out) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!d_imgs || n_frames <= 0) return fail(ctx, ORBGPU_E_EMPTY, "empty image");
   if (!d_kp || !d_desc || !d_n_out) return fail(ctx, ORBGPU_E_INVALID, "null output");
   if (n_frames > ctx->params.max_batch) return fail(ctx, ORBGPU_E_CAPACITY, "n_frames exceeds max_batch");
@@ -723,7 +846,7 @@ int orbgpu_extract_batch_device(orbgpu_ctx *ctx, const uint8_t *d_imgs, int64_t 
 int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_frames, int32_t stride,
                          int32_t feature_count, orbgpu_keypoint *kp, uint8_t *desc, int32_t capacity, int32_t *n_out) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!imgs || n_frames <= 0) return fail(ctx, ORBGPU_E_EMPTY, "empty image");
   for (int f = 0; f < n_frames; f++)
     if (!imgs[f]) return fail(ctx, ORBGPU_E_EMPTY, "empty image");
@@ -736,6 +859,7 @@ int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_
   HIP_TRY(hipSetDevice(ctx->device));
   const LevelGeom &L0 = ctx->geom.lv[0];
   if (!ctx->h_imgs) HIP_TRY(hmalloc(&ctx->h_imgs, (size_t)ctx->params.max_batch * L0.pitch * L0.h));
+  if (n_frames == 1 && ctx->graph_single_frame) return extract_one_frame_graph(ctx, imgs[0], stride, feature_count, kp, desc, capacity, n_out);
   // host -> pinned (pitch layout) -> level 0 of each frame slab.  The row copies of a batch are spread over a few host
   // threads (a frame's upload is enqueued by the thread that staged it; the kernels are enqueued after the join)
   auto stage_frame = [&](int f) -> hipError_t {
@@ -773,6 +897,7 @@ int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_
   HIP_TRY(hipMemcpyAsync(ctx->h_kp_count, ctx->d_out_n, sizeof(int) * n_frames, hipMemcpyDeviceToHost, ctx->stream));
   rc = finish_pipeline(ctx);
   if (rc) return rc;
+
   for (int f = 0; f < n_frames; f++) {
     const int tot = ctx->h_kp_count[f];
     if (tot > cap_dev) return fail(ctx, ORBGPU_E_CAPACITY, "internal keypoint capacity too small: need " + std::to_string(tot));
@@ -827,7 +952,7 @@ int orbgpu_debug_dump(orbgpu_ctx *ctx, int32_t frame, uint8_t *pyramid, uint8_t 
                       int32_t *cand_x, int32_t *cand_y, int32_t *cand_score, int32_t cand_capacity,
                       int32_t *n_cand_per_level) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (frame < 0 || frame >= ctx->last_frames) return fail(ctx, ORBGPU_E_INVALID, "frame outside the last batch");
   const DeviceGeom &g = ctx->geom;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -891,6 +1016,16 @@ int orbgpu_debug_dump(orbgpu_ctx *ctx, int32_t frame, uint8_t *pyramid, uint8_t 
 
 // ---- matching ----------------------------------------------------------------------------------
 
+static bool window_grid_ok(const orbgpu_ctx *ctx, const orbgpu_window_args &a) {
+  return a.to_xy && a.n_to >= 64 && a.n_from >= ctx->window_grid_min_from && a.n_to < (1 << 20) && a.n_from < (1 << 20) &&
+         !ctx->window_plain_scan;
+}
+// one small search: the wave-per-64x64-block kernels, unless a test forces the grid or the exploratory MFMA engine is on
+static bool takes_small_path(const orbgpu_ctx *ctx, const orbgpu_window_args &a) {
+  return match_small_fits(a.n_to, a.n_from) && !(window_grid_ok(ctx, a) && ctx->window_grid_forced) &&
+         !(ctx->bruteforce_mfma && !a.to_xy);
+}
+
 static int match_device_locked(orbgpu_ctx *ctx, const orbgpu_window_args &a, int32_t *d_from_idx, uint32_t *d_dist) {
   if (a.n_to < 0 || a.n_from < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
   if (a.n_from >= (1 << 23)) return fail(ctx, ORBGPU_E_INVALID, "n_from must be below 2^23");
@@ -902,8 +1037,16 @@ static int match_device_locked(orbgpu_ctx *ctx, const orbgpu_window_args &a, int
     HIP_TRY(hipMemsetAsync(d_dist, 0, sizeof(uint32_t) * (size_t)a.n_to, ctx->stream));
     return ORBGPU_OK;
   }
-  if (a.to_xy && a.n_to >= 64 && a.n_from >= ctx->window_grid_min_from && a.n_to < (1 << 20) && a.n_from < (1 << 20) &&
-      !ctx->window_plain_scan) {
+  const bool grid_ok = window_grid_ok(ctx, a);
+  if (takes_small_path(ctx, a)) {
+    // one small search (the per-frame call of the reference's matchers): a wave per 64 x 64 block of pairs
+    int rc = ensure_match_scratch(ctx, match_small_scratch_bytes(a.n_to, a.n_from));
+    if (rc) return rc;
+    launch_match_small(ctx, a, d_from_idx, reinterpret_cast<unsigned *>(d_dist), ctx->d_match_scratch);
+    HIP_TRY(hipGetLastError());
+    return ORBGPU_OK;
+  }
+  if (grid_ok) {
     // windowed search among many 'from' rows (below ~2000 a single search has too few wavefronts for the grid to pay): over the 64 x 48 search grid laid over the context's image (one segment, the same
     // kernels as orbgpu_match_window_grid_segments_device; identical results, see there)
     int rc = ensure_match_scratch(ctx, grid_match_scratch_bytes(1, a.n_to, a.n_from, a.n_from));
@@ -926,7 +1069,7 @@ int orbgpu_match_bruteforce_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, in
                                    int32_t n_from, uint32_t threshold, double ratio, int32_t *d_from_idx_per_to,
                                    uint32_t *d_dist) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if ((n_to > 0 && (!d_to_desc || !d_from_idx_per_to || !d_dist)) || (n_from > 0 && !d_from_desc))
     return fail(ctx, ORBGPU_E_INVALID, "null argument");
   orbgpu_window_args a{};
@@ -937,7 +1080,7 @@ int orbgpu_match_bruteforce_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, in
 
 int orbgpu_set_bruteforce_engine(orbgpu_ctx *ctx, int32_t engine) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (engine != ORBGPU_ENGINE_POPCOUNT && engine != ORBGPU_ENGINE_MFMA_I8)
     return fail(ctx, ORBGPU_E_INVALID, "unknown brute-force engine");
   ctx->bruteforce_mfma = engine == ORBGPU_ENGINE_MFMA_I8;
@@ -948,7 +1091,7 @@ int orbgpu_match_bruteforce_noalloc_device(orbgpu_ctx *ctx, const uint8_t *d_to_
                                            const uint8_t *d_from_desc, int32_t n_from, uint32_t threshold, double ratio,
                                            int32_t *d_from_idx_per_to, uint32_t *d_dist) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (n_to < 0 || n_from < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
   if ((n_to > 0 && (!d_to_desc || !d_from_idx_per_to || !d_dist)) || (n_from > 0 && !d_from_desc))
     return fail(ctx, ORBGPU_E_INVALID, "null argument");
@@ -977,7 +1120,7 @@ int orbgpu_match_bruteforce_noalloc_device(orbgpu_ctx *ctx, const uint8_t *d_to_
 
 int orbgpu_match_window_device(orbgpu_ctx *ctx, const orbgpu_window_args *a, int32_t *d_from_idx_per_to, uint32_t *d_dist) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
   if (a->n_to > 0 && (!a->to_desc || !a->to_xy || !a->to_window || !a->to_min_level || !a->to_max_level ||
                       !d_from_idx_per_to || !d_dist))
@@ -991,7 +1134,7 @@ int orbgpu_match_window_segments_device(orbgpu_ctx *ctx, const orbgpu_window_arg
                                         int32_t n_segments, int32_t max_to_count, int32_t *d_from_idx_per_to,
                                         uint32_t *d_dist) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
   if (n_segments < 0 || max_to_count < 0 || a->n_to < 0 || a->n_from < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
   if (n_segments == 0 || max_to_count == 0) return ORBGPU_OK;
@@ -1015,7 +1158,7 @@ int orbgpu_grid_build_device(orbgpu_ctx *ctx, const double *d_xy, const int32_t 
                              int32_t max_count, double image_width, double image_height, int32_t *d_cell_start,
                              int32_t *d_items) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (n_ranges < 0 || max_count < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
   if (!(image_width > 0.0) || !(image_height > 0.0)) return fail(ctx, ORBGPU_E_INVALID, "image size must be positive");
   if (max_count >= (1 << 20)) return fail(ctx, ORBGPU_E_INVALID, "a grid range must hold fewer than 2^20 rows");
@@ -1035,7 +1178,7 @@ int orbgpu_match_window_grid_segments_device(orbgpu_ctx *ctx, const orbgpu_windo
                                              double image_width, double image_height, int32_t *d_from_idx_per_to,
                                              uint32_t *d_dist) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
   if (n_segments < 0 || max_to_count < 0 || max_from_count < 0 || a->n_to < 0 || a->n_from < 0)
     return fail(ctx, ORBGPU_E_INVALID, "negative count");
@@ -1063,7 +1206,7 @@ int orbgpu_match_window_grid_segments_device(orbgpu_ctx *ctx, const orbgpu_windo
 
 int orbgpu_match_window(orbgpu_ctx *ctx, const orbgpu_window_args *a, int32_t *from_idx_per_to, uint32_t *dist) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
   const bool window = a->to_xy != nullptr;
   if (a->n_to < 0 || a->n_from < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
@@ -1092,11 +1235,18 @@ int orbgpu_match_window(orbgpu_ctx *ctx, const orbgpu_window_args *a, int32_t *f
   d.to_active = a->to_active ? st.put(a->to_active, nt) : nullptr;
   int32_t *d_idx = st.put<int32_t>(nullptr, nt);
   uint32_t *d_dist = st.put<uint32_t>(nullptr, nt);
-  rc = match_device_locked(ctx, d, d_idx, d_dist);
+  HIP_TRY(st.upload());
+  // small results (a few KB): the last kernel writes them straight into the mapped host twin, no copy back
+  const bool direct = nt * 8 <= (64u << 10) && takes_small_path(ctx, d);
+  rc = match_device_locked(ctx, d, direct ? st.mapped_of(d_idx) : d_idx, direct ? st.mapped_of(d_dist) : d_dist);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(from_idx_per_to, d_idx, nt * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(dist, d_dist, nt * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (!direct) {
+    HIP_TRY(st.download(d_idx, nt));
+    HIP_TRY(st.download(d_dist, nt));
+  }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  st.fetch(from_idx_per_to, d_idx, nt);
+  st.fetch(dist, d_dist, nt);
   return ORBGPU_OK;
 }
 
@@ -1113,7 +1263,7 @@ int orbgpu_match_frames_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp, con
                                uint64_t window, uint32_t threshold, double ratio, int32_t check_orientation,
                                int32_t *d_match, uint32_t *d_dist, int32_t *d_n_matches) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (n_pairs < 0 || capacity < 1) return fail(ctx, ORBGPU_E_INVALID, "bad size");
   if (n_pairs == 0) return ORBGPU_OK;
   if (!d_kp || !d_desc || !d_n || !d_to_frame || !d_from_frame || !d_match || !d_dist || !d_n_matches)
@@ -1131,7 +1281,7 @@ int orbgpu_match_frames_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp, con
 int orbgpu_match_groups_device(orbgpu_ctx *ctx, const orbgpu_group_args *a, int32_t n_slots, int32_t *d_from_idx_per_to,
                                uint32_t *d_dist) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
   if (a->n_to < 0 || a->n_from < 0 || a->n_groups < 0 || n_slots < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
   if (a->n_to == 0) return ORBGPU_OK;
@@ -1150,11 +1300,12 @@ int orbgpu_match_groups(orbgpu_ctx *ctx, const orbgpu_group_args *a, int32_t *fr
   if (!ctx) return ORBGPU_E_INVALID;
   int n_slots = 0, n_cand = 0;
   orbgpu_group_args d{};
+  std::lock_guard<std::recursive_mutex> hold(ctx->mu);  // the staging buffers are the context's: held to the last copy
   Staging st{ctx};
   int32_t *d_idx = nullptr;
   uint32_t *d_dist = nullptr;
   {
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
     if (a->n_to < 0 || a->n_from < 0 || a->n_groups < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
     if (a->n_to == 0) return ORBGPU_OK;
@@ -1190,10 +1341,11 @@ int orbgpu_match_groups(orbgpu_ctx *ctx, const orbgpu_group_args *a, int32_t *fr
     }
     d_idx = st.put<int32_t>(nullptr, nt);
     d_dist = st.put<uint32_t>(nullptr, nt);
+    HIP_TRY(st.upload());
   }
   int rc = orbgpu_match_groups_device(ctx, &d, n_slots, d_idx, d_dist);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   HIP_TRY(hipMemcpyAsync(from_idx_per_to, d_idx, (size_t)a->n_to * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(dist, d_dist, (size_t)a->n_to * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1211,7 +1363,7 @@ int orbgpu_keypoint_geometry_device(orbgpu_ctx *ctx, const orbgpu_camera *camera
                                     const int32_t *d_n, int32_t n_frames, int32_t capacity, double *d_undistorted,
                                     double *d_unprojected, uint8_t *d_ok) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   int rc = check_camera(ctx, camera);
   if (rc) return rc;
   if (n_frames < 0 || capacity < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
@@ -1226,7 +1378,7 @@ int orbgpu_keypoint_geometry_device(orbgpu_ctx *ctx, const orbgpu_camera *camera
 int orbgpu_keypoint_geometry(orbgpu_ctx *ctx, const orbgpu_camera *camera, const orbgpu_keypoint *kp, int32_t n,
                              double *undistorted, double *unprojected, uint8_t *ok) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   int rc = check_camera(ctx, camera);
   if (rc) return rc;
   if (n < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
@@ -1240,6 +1392,7 @@ int orbgpu_keypoint_geometry(orbgpu_ctx *ctx, const orbgpu_camera *camera, const
   double *d_und = st.put<double>(nullptr, (size_t)n * 2);
   double *d_unp = st.put<double>(nullptr, (size_t)n * 3);
   uint8_t *d_ok = st.put<uint8_t>(nullptr, (size_t)n);
+  HIP_TRY(st.upload());
   launch_keypoint_geometry(ctx, *camera, d_kp, nullptr, 1, n, d_und, d_unp, d_ok);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(undistorted, d_und, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1252,7 +1405,7 @@ int orbgpu_keypoint_geometry(orbgpu_ctx *ctx, const orbgpu_camera *camera, const
 int orbgpu_distinctive_descriptor_device(orbgpu_ctx *ctx, const uint8_t *d_desc, const int32_t *d_offsets, int32_t n_points,
                                          int32_t *d_best_index) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (n_points < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
   if (n_points == 0) return ORBGPU_OK;
   if (!d_offsets || !d_best_index) return fail(ctx, ORBGPU_E_INVALID, "null argument");
@@ -1275,21 +1428,23 @@ int orbgpu_distinctive_descriptor(orbgpu_ctx *ctx, const uint8_t *desc, const in
   }
   const size_t total = (size_t)offsets[n_points];
   if (total > 0 && !desc) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> hold(ctx->mu);
   Staging st{ctx};
   uint8_t *d_desc;
   int32_t *d_off, *d_best;
   {
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = st.reserve(pad256(total * 32) + pad256(((size_t)n_points + 1) * 4) + pad256((size_t)n_points * 4) + 1024);
     if (rc) return rc;
     d_desc = st.put(desc, total * 32);
     d_off = st.put(offsets, (size_t)n_points + 1);
     d_best = st.put<int32_t>(nullptr, (size_t)n_points);
+    HIP_TRY(st.upload());
   }
   int rc = orbgpu_distinctive_descriptor_device(ctx, d_desc, d_off, n_points, d_best);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   HIP_TRY(hipMemcpyAsync(best_index, d_best, (size_t)n_points * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return ORBGPU_OK;
@@ -1298,7 +1453,7 @@ int orbgpu_distinctive_descriptor(orbgpu_ctx *ctx, const uint8_t *desc, const in
 int orbgpu_vocab_create(orbgpu_ctx *ctx, int32_t n_nodes, const int32_t *child_off, const uint32_t *children,
                         const uint8_t *node_desc, const uint32_t *word_id, int32_t levels, orbgpu_vocab **out) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!out) return fail(ctx, ORBGPU_E_INVALID, "null argument");
   *out = nullptr;
   if (n_nodes < 1 || levels < 0 || !child_off || !node_desc || !word_id) return fail(ctx, ORBGPU_E_INVALID, "bad vocabulary");
@@ -1343,7 +1498,7 @@ void orbgpu_vocab_destroy(orbgpu_vocab *v) {
 int orbgpu_bow_transform_device(orbgpu_ctx *ctx, const orbgpu_vocab *vocab, const uint8_t *d_desc, int32_t n, int32_t levelsup,
                                 uint32_t *d_word_id_out, uint32_t *d_node_id_out) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!vocab || vocab->ctx != ctx) return fail(ctx, ORBGPU_E_INVALID, "vocabulary belongs to another context");
   if (n < 0 || levelsup < 0) return fail(ctx, ORBGPU_E_INVALID, "negative argument");
   if (n == 0) return ORBGPU_OK;
@@ -1360,21 +1515,23 @@ int orbgpu_bow_transform(orbgpu_ctx *ctx, const orbgpu_vocab *vocab, const uint8
   if (n < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
   if (n == 0) return ORBGPU_OK;
   if (!desc || !word_id_out || !node_id_out) return fail(ctx, ORBGPU_E_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> hold(ctx->mu);
   Staging st{ctx};
   uint8_t *d_desc;
   uint32_t *d_w, *d_n;
   {
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = st.reserve(pad256((size_t)n * 32) + 2 * pad256((size_t)n * 4) + 1024);
     if (rc) return rc;
     d_desc = st.put(desc, (size_t)n * 32);
     d_w = st.put<uint32_t>(nullptr, (size_t)n);
     d_n = st.put<uint32_t>(nullptr, (size_t)n);
+    HIP_TRY(st.upload());
   }
   int rc = orbgpu_bow_transform_device(ctx, vocab, d_desc, n, levelsup, d_w, d_n);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   HIP_TRY(hipMemcpyAsync(word_id_out, d_w, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(node_id_out, d_n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1383,7 +1540,7 @@ int orbgpu_bow_transform(orbgpu_ctx *ctx, const orbgpu_vocab *vocab, const uint8
 
 int orbgpu_bow_score_device(orbgpu_ctx *ctx, const orbgpu_bow_score_args *a, uint64_t *d_shared_words, double *d_score) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!a) return fail(ctx, ORBGPU_E_INVALID, "null argument");
   if (a->n_q < 0 || a->n_keyframes < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
   if (a->scoring < 0 || a->scoring > 5 || a->scoring == 3)
@@ -1418,12 +1575,13 @@ int orbgpu_bow_score(orbgpu_ctx *ctx, const orbgpu_bow_score_args *a, uint64_t *
         return fail(ctx, ORBGPU_E_INVALID, "keyframe words must be strictly ascending inside a keyframe");
   }
   const size_t total = (size_t)a->kf_offsets[a->n_keyframes], nq = (size_t)a->n_q, nk = (size_t)a->n_keyframes;
+  std::lock_guard<std::recursive_mutex> hold(ctx->mu);
   Staging st{ctx};
   orbgpu_bow_score_args d = *a;
   unsigned long long *d_shared;
   double *d_score;
   {
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = st.reserve(pad256(nq * 4) * 2 + pad256(nq * 8) + pad256((nk + 1) * 8) + pad256(total * 4) * 2 + pad256(total * 8) +
                         2 * pad256(nk * 8) + 4096);
@@ -1437,10 +1595,11 @@ int orbgpu_bow_score(orbgpu_ctx *ctx, const orbgpu_bow_score_args *a, uint64_t *
     d.kf_counts = (total && a->kf_counts) ? st.put(a->kf_counts, total) : nullptr;
     d_shared = st.put<unsigned long long>(nullptr, nk);
     d_score = st.put<double>(nullptr, nk);
+    HIP_TRY(st.upload());
   }
   int rc = orbgpu_bow_score_device(ctx, &d, reinterpret_cast<uint64_t *>(d_shared), d_score);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   HIP_TRY(hipMemcpyAsync(shared_words, d_shared, nk * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(score, d_score, nk * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1506,7 +1665,7 @@ int bowdb_reserve(orbgpu_bowdb *db, long long need) {
 
 int orbgpu_bowdb_create(orbgpu_ctx *ctx, int32_t scoring, int32_t with_counts, orbgpu_bowdb **out) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!out) return fail(ctx, ORBGPU_E_INVALID, "null argument");
   *out = nullptr;
   if (!scoring_ok(scoring))
@@ -1533,7 +1692,7 @@ void orbgpu_bowdb_destroy(orbgpu_bowdb *db) {
 
 int orbgpu_bowdb_size(const orbgpu_bowdb *db, int32_t *n_keyframes) {
   if (!db || !n_keyframes) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(db->ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(db->ctx->mu);
   *n_keyframes = (int32_t)db->ids.size();
   return ORBGPU_OK;
 }
@@ -1541,7 +1700,7 @@ int orbgpu_bowdb_size(const orbgpu_bowdb *db, int32_t *n_keyframes) {
 int orbgpu_bowdb_erase(orbgpu_bowdb *db, uint64_t keyframe_id) {
   if (!db) return ORBGPU_E_INVALID;
   orbgpu_ctx *ctx = db->ctx;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   auto it = db->slot_of.find(keyframe_id);
   if (it == db->slot_of.end()) return ORBGPU_OK;
   const int slot = it->second, last = (int)db->ids.size() - 1;
@@ -1565,7 +1724,7 @@ int orbgpu_bowdb_append(orbgpu_bowdb *db, uint64_t keyframe_id, const uint32_t *
   if (!db) return ORBGPU_E_INVALID;
   orbgpu_ctx *ctx = db->ctx;
   {
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (n_words < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
     if (n_words > 0 && (!words || !values)) return fail(ctx, ORBGPU_E_INVALID, "null argument");
     if (counts && !db->with_counts) return fail(ctx, ORBGPU_E_INVALID, "this database was created without word counts");
@@ -1574,7 +1733,7 @@ int orbgpu_bowdb_append(orbgpu_bowdb *db, uint64_t keyframe_id, const uint32_t *
   }
   int rc = orbgpu_bowdb_erase(db, keyframe_id);  // an id that is present is replaced
   if (rc) return rc;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
   rc = bowdb_reserve(db, n_words);
   if (rc) return rc;
@@ -1608,7 +1767,7 @@ int orbgpu_bowdb_query(orbgpu_bowdb *db, const uint32_t *q_words, const double *
                        int32_t *n_out) {
   if (!db) return ORBGPU_E_INVALID;
   orbgpu_ctx *ctx = db->ctx;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (!n_out) return fail(ctx, ORBGPU_E_INVALID, "null argument");
   *n_out = 0;
   if (n_q < 0 || capacity < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
@@ -1693,7 +1852,7 @@ int orbgpu_match_allpairs_device(orbgpu_ctx *ctx, const orbgpu_keypoint *d_kp_ro
                                  int32_t row_offset, uint32_t threshold, double ratio, int32_t check_orientation,
                                  int32_t *d_n_matches, int32_t *d_match) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   return match_allpairs_locked(ctx, d_kp_rows ? &d_kp_rows->angle : nullptr, d_desc_rows, d_n_rows, n_rows,
                                d_kp_cols ? &d_kp_cols->angle : nullptr, (int)sizeof(orbgpu_keypoint), d_desc_cols, d_n_cols,
                                n_cols, capacity, row_offset, threshold, ratio, check_orientation, d_n_matches, d_match);
@@ -1705,7 +1864,7 @@ int orbgpu_match_allpairs_angles_device(orbgpu_ctx *ctx, const float *d_angle_ro
                                         int32_t capacity, int32_t row_offset, uint32_t threshold, double ratio,
                                         int32_t check_orientation, int32_t *d_n_matches, int32_t *d_match) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   return match_allpairs_locked(ctx, d_angle_rows, d_desc_rows, d_n_rows, n_rows, d_angle_cols, (int)sizeof(float), d_desc_cols,
                                d_n_cols, n_cols, capacity, row_offset, threshold, ratio, check_orientation, d_n_matches,
                                d_match);
@@ -1714,7 +1873,7 @@ int orbgpu_match_allpairs_angles_device(orbgpu_ctx *ctx, const float *d_angle_ro
 int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to, const float *angle_from, int32_t n_from,
                            int32_t *match, int32_t *n_discarded) {
   if (!ctx) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   if (n_to < 0 || n_from < 0) return fail(ctx, ORBGPU_E_INVALID, "negative count");
   if (n_discarded) *n_discarded = 0;
   if (n_to == 0) return ORBGPU_OK;
@@ -1729,6 +1888,7 @@ int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to,
   float *d_from = st.put(angle_from, (size_t)n_from);
   int32_t *d_m = st.put(match, (size_t)n_to);
   int32_t *d_nd = st.put<int32_t>(nullptr, 1);
+  HIP_TRY(st.upload());
   launch_rotation_filter(ctx, d_to, n_to, d_from, d_m, d_nd);
   HIP_TRY(hipGetLastError());
   int32_t nd = 0;
@@ -1741,7 +1901,7 @@ int orbgpu_rotation_filter(orbgpu_ctx *ctx, const float *angle_to, int32_t n_to,
 
 int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms8) {
   if (!ctx || !ms8) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   int rc = finish_pipeline(ctx);
   if (rc) return rc;
   for (int i = 0; i < 8; i++) ms8[i] = ctx->stage_ms[i];
@@ -1750,7 +1910,7 @@ int orbgpu_stage_times(orbgpu_ctx *ctx, float *ms8) {
 
 int orbgpu_popcount_peak(orbgpu_ctx *ctx, double *pairs_per_second) {
   if (!ctx || !pairs_per_second) return ORBGPU_E_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   HIP_TRY(hipSetDevice(ctx->device));
   *pairs_per_second = run_popcount_peak(ctx);
   HIP_TRY(hipGetLastError());

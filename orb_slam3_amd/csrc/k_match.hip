@@ -309,6 +309,98 @@ __global__ __launch_bounds__(256) void k_snn_resolve(int n_to, int *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// ONE small search (n_to * n_from up to a few million pairs): the call SNNMatcher<ProjectionSearchIterator> /
+// SNNMatcher<AreaToIterator> makes once per frame (monocular_frame.cpp:173-189, :285-306).  k_snn_partial gives such a
+// problem a handful of workgroups that each walk hundreds of 'from' rows (70 us for 1000 x 1000); here a WAVE owns 64
+// 'to' rows x 64 'from' rows, so 1000 x 1000 is 256 independent waves of 64 short iterations.  The wave's 64 'from' rows
+// are loaded once, one row per lane (coalesced), and broadcast lane by lane with v_readlane; the window / level
+// predicate comes first and rows that no lane can see (__ballot) skip the distance.  Three short launches: partial
+// (which also resets the claims of its 'from' rows), finalize (merge of the chunks, threshold, ratio, claims), resolve
+// (uniqueness; writes the caller's arrays, which may be mapped host memory).
+template <bool WINDOW>
+__global__ __launch_bounds__(64) void k_snn_small(orbgpu_window_args a, uint2 *__restrict__ partial,
+                                                  unsigned long long *__restrict__ claim) {
+  const int lane = threadIdx.x;
+  const int j0 = blockIdx.y * 64;
+  const int nj = min(64, a.n_from - j0);
+  if (blockIdx.x == 0 && lane < nj) claim[j0 + lane] = ~0ull;
+  const int row = blockIdx.x * 64 + lane;
+  const int ii = min(row, a.n_to - 1);
+  const uint4 *td = reinterpret_cast<const uint4 *>(a.to_desc) + 2 * (size_t)ii;
+  const uint4 t0 = td[0], t1 = td[1];
+  const unsigned t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+  ToWindow tw{};
+  if (WINDOW) {
+    tw.x = a.to_xy[2 * (size_t)ii];
+    tw.y = a.to_xy[2 * (size_t)ii + 1];
+    tw.win = (double)a.to_window[ii];
+    tw.lmin = a.to_min_level[ii];
+    tw.lmax = a.to_max_level[ii];
+    tw.check_levels = (tw.lmin > 0) || (tw.lmax >= 0);  // features.cpp:94
+  }
+  const int jj = j0 + min(lane, nj - 1);
+  const uint4 *fdp = reinterpret_cast<const uint4 *>(a.from_desc) + 2 * (size_t)jj;
+  const uint4 fa = fdp[0], fb = fdp[1];
+  double2 fp = make_double2(0, 0);
+  int flv = 0;
+  if (WINDOW) {
+    fp = reinterpret_cast<const double2 *>(a.from_xy)[jj];
+    flv = a.from_level[jj];
+  }
+  auto bcast = [](unsigned v, int u) { return (unsigned)__builtin_amdgcn_readlane((int)v, u); };
+  auto bcast_d = [&](double v, int u) {
+    const unsigned lo = bcast((unsigned)__double2loint(v), u), hi = bcast((unsigned)__double2hiint(v), u);
+    return __hiloint2double((int)hi, (int)lo);
+  };
+  unsigned best = KEY_NONE, second = KEY_NONE;
+  for (int u = 0; u < nj; u++) {
+    bool ok = true;
+    if (WINDOW) {
+      const double2 p = make_double2(bcast_d(fp.x, u), bcast_d(fp.y, u));
+      ok = window_ok(tw, p, (int)bcast((unsigned)flv, u));
+      if (!__ballot(ok)) continue;
+    }
+    const uint4 ca = make_uint4(bcast(fa.x, u), bcast(fa.y, u), bcast(fa.z, u), bcast(fa.w, u));
+    const uint4 cb = make_uint4(bcast(fb.x, u), bcast(fb.y, u), bcast(fb.z, u), bcast(fb.w, u));
+    unsigned key = (hamming8(t, ca, cb) << IDX_BITS) | (unsigned)(j0 + u);
+    key = ok ? key : KEY_NONE;
+    second = umed3(best, key, second);
+    best = min(best, key);
+  }
+  if (row < a.n_to) partial[(size_t)blockIdx.y * a.n_to + row] = make_uint2(best, second);
+}
+
+__global__ __launch_bounds__(256) void k_snn_small_finalize(const uint2 *__restrict__ partial, int n_chunks, int n_to,
+                                                            const uint8_t *__restrict__ to_active, unsigned threshold,
+                                                            double ratio, uint2 *__restrict__ accepted,
+                                                            unsigned long long *__restrict__ claim) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_to) return;
+  unsigned best = KEY_NONE, second = KEY_NONE;
+  for (int c = 0; c < n_chunks; c++) {
+    const uint2 p = partial[(size_t)c * n_to + i];
+    merge_keys(best, second, p.x, p.y);
+  }
+  unsigned d = 0;
+  int j = snn_accept(best, second, threshold, ratio, d);
+  if (to_active && !to_active[i]) j = -1;
+  accepted[i] = make_uint2((unsigned)j, d);
+  if (j >= 0) atomicMin(&claim[j], ((unsigned long long)d << 32) | (unsigned)i);
+}
+
+__global__ __launch_bounds__(256) void k_snn_small_resolve(int n_to, const uint2 *__restrict__ accepted,
+                                                           const unsigned long long *__restrict__ claim,
+                                                           int *__restrict__ from_idx, unsigned *__restrict__ dist) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_to) return;
+  const uint2 acc = accepted[i];
+  int j = (int)acc.x;
+  if (j >= 0 && claim[j] != (((unsigned long long)acc.y << 32) | (unsigned)i)) j = -1;
+  from_idx[i] = j;
+  dist[i] = acc.y;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Many independent window searches in one launch (search by projection over a batch of frames: one
 // SNNMatcher<ProjectionSearchIterator>::MatchWithIterators per segment, monocular_frame.cpp:285-306).  Segment s pairs
 // the 'to' rows [to_begin, to_begin + to_count) with the 'from' rows [from_begin, from_begin + from_count) of the
@@ -1393,6 +1485,30 @@ static int pick_chunks(int n_to, int n_from, int &chunk, int max_chunks = INT_MA
   chunk = (n_from + n_chunks - 1) / n_chunks;
   n_chunks = (n_from + chunk - 1) / std::max(chunk, 1);
   return std::max(n_chunks, 1);
+}
+
+// the small-problem path (k_snn_small): scratch = claims, per-chunk partials, accepted pairs
+bool match_small_fits(int n_to, int n_from) { return n_to > 0 && n_from > 0 && (long long)n_to * n_from <= (4ll << 20); }
+size_t match_small_scratch_bytes(int n_to, int n_from) {
+  const size_t n_chunks = (size_t)(n_from + 63) / 64;
+  return pad256((size_t)n_from * 8) + pad256(n_chunks * (size_t)n_to * 8) + pad256((size_t)n_to * 8);
+}
+void launch_match_small(const orbgpu_ctx *c, const orbgpu_window_args &a, int *out_from_idx, unsigned *out_dist, void *scratch) {
+  const int n_chunks = (a.n_from + 63) / 64;
+  char *p = reinterpret_cast<char *>(scratch);
+  unsigned long long *claim = reinterpret_cast<unsigned long long *>(p);
+  p += pad256((size_t)a.n_from * 8);
+  uint2 *partial = reinterpret_cast<uint2 *>(p);
+  p += pad256((size_t)n_chunks * (size_t)a.n_to * 8);
+  uint2 *accepted = reinterpret_cast<uint2 *>(p);
+  const dim3 grid((a.n_to + 63) / 64, n_chunks);
+  if (a.to_xy) hipLaunchKernelGGL((k_snn_small<true>), grid, dim3(64), 0, c->stream, a, partial, claim);
+  else hipLaunchKernelGGL((k_snn_small<false>), grid, dim3(64), 0, c->stream, a, partial, claim);
+  const unsigned th = std::min(a.threshold, 256u);
+  hipLaunchKernelGGL(k_snn_small_finalize, dim3((a.n_to + 255) / 256), dim3(256), 0, c->stream, partial, n_chunks, a.n_to,
+                     a.to_active, th, a.ratio, accepted, claim);
+  hipLaunchKernelGGL(k_snn_small_resolve, dim3((a.n_to + 255) / 256), dim3(256), 0, c->stream, a.n_to, accepted, claim,
+                     out_from_idx, out_dist);
 }
 
 size_t match_scratch_size(int n_to, int n_from) {

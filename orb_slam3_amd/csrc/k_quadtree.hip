@@ -790,15 +790,33 @@ __device__ __forceinline__ void qt_run(const DeviceGeom &g, const QtArgs &a, con
     if (tid == 0) *(volatile int *)a.error_flag = 3;
     Sz = 0;
   }
+  // A presorted level orders its keys by the depth-R quadrant code.  When phase 1 stops before round R (the list did not
+  // grow: every multi-key node kept all its keys in one quadrant, :422) a node's keys are ordered deeper than the node
+  // is, i.e. no longer in candidate order, so "first" among equal responses is then decided by the candidate order
+  // itself: cells row-major, raster order inside a cell (:244-276; a cell's keypoints have x - 3 in
+  // [j * wCell, (j + 1) * wCell), likewise y)
+  const bool by_cand_order = !IN_LDS && R > 0 && rnd < R;
+  auto cand_order = [&L](unsigned key) -> u64 {
+    const int x = (int)key_x(key), y = (int)key_y(key);
+    const int cx = max(x - 3, 0) / L.wcell, cy = max(y - 3, 0) / L.hcell;
+    return ((u64)(unsigned)(cy * L.ncols + cx) << 24) | ((u64)(unsigned)y << 12) | (u64)(unsigned)x;
+  };
   for (int i = tid; i < Sz; i += NT) {
     const QNode P = S.cur[i];
     const KT *keys = (P.cnt >> 31) ? keys1 : keys0;
     const int cnt = (int)(P.cnt & 0x7fffffffu);
     unsigned best = keys[P.beg];
+    if (!by_cand_order) {
 #pragma unroll 4
-    for (int k = 1; k < cnt; k++) {
-      const unsigned key = keys[P.beg + k];
-      if (key_resp(key) > key_resp(best)) best = key;
+      for (int k = 1; k < cnt; k++) {
+        const unsigned key = keys[P.beg + k];
+        if (key_resp(key) > key_resp(best)) best = key;
+      }
+    } else {
+      for (int k = 1; k < cnt; k++) {
+        const unsigned key = keys[P.beg + k];
+        if (key_resp(key) > key_resp(best) || (key_resp(key) == key_resp(best) && cand_order(key) < cand_order(best))) best = key;
+      }
     }
     out[i] = make_short2((short)(key_x(best) + ORB_MIN_BORDER), (short)(key_y(best) + ORB_MIN_BORDER));
   }

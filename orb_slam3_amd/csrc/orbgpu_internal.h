@@ -110,7 +110,7 @@ struct orbgpu_ctx {
   hipStream_t slice_l0[MAX_SLICES]{};      // level 0's FAST launch of a slice runs beside its resize chain
   hipStream_t slice_blur[MAX_SLICES]{};    // the blur of a slice runs beside its (latency-bound) quadtree kernel
   hipEvent_t slice_ev[MAX_SLICES][5]{};    // fork / blur-may-start / slice-done
-  std::mutex mu;
+  std::recursive_mutex mu;  // recursive: host-pointer entry points hold it while they call their *_device twins
   std::string err;
 
   // device slabs, sized for max_batch frames
@@ -171,6 +171,16 @@ struct orbgpu_ctx {
   int ev_head = 0, ev_pending = 0;
   bool ev_full[ORBGPU_EV_SETS]{};      // that set holds every stage boundary, not only the FAST kernel's and the total
   int window_grid_min_from = 2048;  // orbgpu_match_window[_device]: n_from from which the search grid is used
+  bool window_grid_forced = false;  // ORBGPU_WINDOW_GRID_MIN was given: the grid also where the small-problem path would run
+  // host-pointer entry points stage through ONE persistent pair of buffers per context, grown on demand: pinned + mapped
+  // host memory (inputs packed here, small results written here by the kernels) and its device twin (one H2D copy)
+  char *h_stage = nullptr, *h_stage_dev = nullptr, *d_stage = nullptr;
+  size_t stage_bytes = 0;
+  // one frame per host call (orbgpu_extract): the whole call as one captured graph, results in mapped host memory
+  bool graph_single_frame = true;      // ORBGPU_NO_GRAPH=1: eager launches instead
+  hipGraphExec_t graph_one = nullptr;  // upload + pipeline of one frame for graph_one_features keypoints
+  int graph_one_features = 0;
+  char *h_one = nullptr, *h_one_dev = nullptr;  // mapped host memory: keypoints, descriptors, count of that frame
   bool window_plain_scan = false;  // ORBGPU_WINDOW_SCAN=1: orbgpu_match_window[_device] never uses the search grid
   bool link_plain_scan = false;   // ORBGPU_LINK_SCAN=1: large-capacity links by the plain predicated scan (comparison)
   bool bruteforce_mfma = false;  // exploratory engine of the brute-force matcher (orbgpu_set_bruteforce_engine)
@@ -235,6 +245,11 @@ size_t match_scratch_size(int n_to, int n_from);
 // scratch holds match_scratch_size() bytes, or -- with max_chunks limiting the split of the 'from' range -- less
 void launch_match(const orbgpu_ctx *c, const orbgpu_window_args &a /* device pointers; to_xy==NULL => brute force */,
                   int *d_from_idx, unsigned *d_dist, void *scratch, int max_chunks = 0x7fffffff, bool mfma = false);
+// one small search (n_to * n_from <= 4 Mi pairs): a wave per 64 x 64 block of pairs, three short launches; the outputs may
+// be mapped host memory (written once, by the last launch)
+bool match_small_fits(int n_to, int n_from);
+size_t match_small_scratch_bytes(int n_to, int n_from);
+void launch_match_small(const orbgpu_ctx *c, const orbgpu_window_args &a, int *out_from_idx, unsigned *out_dist, void *scratch);
 // fixed per-GPU scratch of orbgpu_match_bruteforce_noalloc_device (a __device__ array in k_match.hip)
 constexpr size_t ORBGPU_NOALLOC_SCRATCH_BYTES = 8u << 20;
 constexpr int ORBGPU_NOALLOC_MAX_DEVICES = 64;

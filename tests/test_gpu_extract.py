@@ -105,6 +105,20 @@ def _scene(kind, seed, h, w):
         return img
     if kind == "noise":            # white noise: candidates everywhere
         return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if kind in ("tie_cluster", "tie_clusters"):
+        # black frame with one or two tight clusters of identical blobs (3 x 3 of 180 around a 255 centre: one corner of
+        # score 254 each).  All keys of a cluster fall into one quadrant round after round, so the node list stops
+        # growing at once (orb_feature_extractor.cpp:422) and the final node holds equal responses; the cluster
+        # straddles a depth-2 quadrant boundary (x = 152 + 16) inside one FAST cell, with its first corner in candidate
+        # order to the right of it -- a key order by deeper quadrant code would put another corner first
+        img = np.zeros((h, w), np.uint8)
+        pts = [(170, 91), (179, 91), (153, 100), (162, 100), (171, 100), (150, 109), (159, 109), (168, 109)]
+        if kind == "tie_clusters":
+            pts = pts + [(x + w // 2 - 20, y + h // 2 + 10) for x, y in pts]
+        for x, y in pts:
+            img[y - 1:y + 2, x - 1:x + 2] = 180
+            img[y, x] = 255
+        return img
     return synth.frame(seed, h, w)
 
 
@@ -221,6 +235,9 @@ def test_resize_kernels_agree(oracle, monkeypatch):
     (640, 480, 1000, 8, 37, "checker"),    # exact ties: equal responses inside a node (first maximum by candidate order)
     (640, 480, 2000, 8, 38, "noise"),      # cells with far more than 16 candidates
     (640, 480, 800, 8, 39, "gradient"),    # most cells and most codes empty
+    (640, 480, 1000, 8, 40, "tie_cluster"),   # phase 1 stops before the presorted depth: ties inside a node whose keys are
+    (640, 480, 1000, 8, 41, "tie_clusters"),  # ordered deeper than the node (first maximum must follow candidate order)
+    (1920, 1080, 5000, 8, 42, "tie_clusters"),
 ])
 def test_extract_quadtree_presorted(oracle, monkeypatch, w, h, nfeat, levels, seed, scene):
     """the presort of the quadtree's first rounds (k_qt_presort, by default for levels of 0.4 Mpx and more) forced for
