@@ -275,3 +275,26 @@ def test_resize_nest_agrees(oracle, monkeypatch, w, h, plan):
     _kp_equal(ft.keypoints, okp)
     assert np.array_equal(ft.descriptors, odesc)
     fe.close()
+
+
+def test_single_frame_graph_recapture_and_eager(oracle, monkeypatch):
+    """orbgpu_extract replays ONE captured hipGraph per feature_count (results land in mapped host memory): a context asked
+    for 500, then 1000, then 500 keypoints again re-captures each time and stays bit-exact, the frame changes between
+    replays of one graph, and ORBGPU_NO_GRAPH=1 (eager launches, copies back) gives the same."""
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    w, h = 640, 480
+    frames = synth.sequence(61, 3, h, w)
+    p = oracle.params(w, h)
+    want = {(f, nf): oracle.extract(p, frames[f], nf) for f in range(3) for nf in (500, 1000)}
+    for no_graph in (None, "1"):
+        if no_graph:
+            monkeypatch.setenv("ORBGPU_NO_GRAPH", no_graph)
+        fe = ORBFeatureExtractor(w, h, 1.2, 8, 20, 7, max_features=1000)
+        for f, nf in ((0, 500), (1, 500), (2, 1000), (0, 1000), (1, 500), (2, 500), (0, 1000)):
+            ft = Features(w, h)
+            assert fe.Extract(frames[f], ft, nf) == 0
+            okp, odesc = want[(f, nf)]
+            _kp_equal(ft.keypoints, okp)
+            same = np.array_equal(ft.descriptors, odesc)
+            assert same, (no_graph, f, nf)
+        fe.close()
