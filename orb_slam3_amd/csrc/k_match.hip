@@ -512,6 +512,7 @@ __device__ __forceinline__ int hilbert64(int x, int y) {
 // items[out + k] = row - begin in bin order, cell_start[r * (GRID_CELLS + 1) + c] (not CURVE), and with GATHER the
 // rows' descriptor / position / level copied into bin order (the matcher then scans contiguous arrays).
 constexpr int GB_THREADS = 1024, GB_PER = GRID_BINS / GB_THREADS;
+constexpr int GB_RANK_LIMIT = 4096;  // largest bin that is still ordered by rank counting (quadratic in the bin)
 
 struct GridBuildArgs {
   const double2 *xy;
@@ -528,12 +529,13 @@ struct GridBuildArgs {
 };
 
 // count rows, of which keep(i) take part; getxy(i) = position; emit(k, i): row i is the k-th of the binned order.
-// Returns the number of rows kept.  hist / cursor: GRID_BINS ints each, wsum: GB_THREADS / 64 + 1.
+// Returns the number of rows kept.  hist / cursor: GRID_BINS ints each, wsum: GB_THREADS / 64 + 2.
 template <bool CURVE, class GetXY, class Keep, class Emit>
 __device__ __forceinline__ int grid_build_core(int count, const GridDims &g, int *__restrict__ tmp, int *cell_start_r,
                                                int *hist, int *cursor, int *wsum, GetXY getxy, Keep keep, Emit emit) {
   const int tid = threadIdx.x;
   for (int b = tid; b < GRID_BINS; b += GB_THREADS) hist[b] = 0;
+  if (tid == 0) wsum[GB_THREADS / 64 + 1] = 0;  // size of the largest bin when it is above GB_RANK_LIMIT
   __syncthreads();
   auto bin_of = [&](int i) {
     const double2 p = getxy(i);
@@ -567,11 +569,45 @@ __device__ __forceinline__ int grid_build_core(int count, const GridDims &g, int
 #pragma unroll
   for (int k = 0; k < GB_PER; k++) cursor[tid * GB_PER + k] = base + local[k];
   if (tid == GB_THREADS - 1) wsum[GB_THREADS / 64] = base + sum;
+  // the largest bin decides how rows are ordered inside the bins (below)
+  int hmax = 0;
+#pragma unroll
+  for (int k = 0; k < GB_PER; k++) hmax = max(hmax, hist[tid * GB_PER + k]);
+  if (hmax > GB_RANK_LIMIT) atomicMax(&wsum[GB_THREADS / 64 + 1], hmax);
   __syncthreads();
   const int total = wsum[GB_THREADS / 64];
+  const bool crowded = wsum[GB_THREADS / 64 + 1] > GB_RANK_LIMIT;
   if (!CURVE && cell_start_r) {
     for (int b = tid; b < GRID_CELLS; b += GB_THREADS) cell_start_r[b] = cursor[b];
     if (tid == 0) cell_start_r[GRID_CELLS] = total;
+  }
+  if (crowded) {
+    // A bin holds thousands of rows (keypoints of a larger image than the grid was laid over all clamp into the last
+    // cells; a clustered point set): ranking by counting below is quadratic in the bin.  Stable placement instead, by ONE
+    // wave walking the rows in index order, 64 at a time: the lanes of one bin are found with a ballot, their rank is
+    // their position among them, the first of them advances the bin's cursor.  Linear in the rows; slow (one wave), but
+    // only ever taken by inputs the grid is a poor index for.
+    __syncthreads();
+    if (tid < 64) {
+      const unsigned long long below = (1ull << tid) - 1ull;
+      for (int base0 = 0; base0 < count; base0 += 64) {
+        const int i = base0 + tid;
+        const bool valid = i < count && keep(i);
+        const int b = valid ? bin_of(i) : -1;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const int bl = __builtin_amdgcn_readlane(b, leader);
+          const unsigned long long m = __ballot(b == bl);
+          const int start = cursor[bl];
+          if (b == bl) emit(start + __popcll(m & below), i);
+          if (tid == leader) cursor[bl] = start + __popcll(m);
+          todo &= ~m;
+        }
+      }
+    }
+    __syncthreads();
+    return total;
   }
   for (int i = tid; i < count; i += GB_THREADS) {
     if (!keep(i)) continue;
@@ -618,14 +654,14 @@ __device__ __forceinline__ void grid_build_body(const GridBuildArgs &a, const Gr
 
 // the grid by itself (orbgpu_grid_build_device): grid = ranges
 __global__ __launch_bounds__(GB_THREADS) void k_grid_build(GridBuildArgs a, GridDims g) {
-  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64 + 1];
+  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64 + 2];
   grid_build_body<false, false>(a, g, blockIdx.x, hist, cursor, wsum);
 }
 
 // both sides of a batch of window searches in one launch: grid = (segments, 2); y = 0 bins the 'from' rows by cell and
 // gathers their copies, y = 1 orders the 'to' rows along the curve
 __global__ __launch_bounds__(GB_THREADS) void k_grid_build_pair(GridBuildArgs from, GridBuildArgs to, GridDims g) {
-  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64 + 1];
+  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64 + 2];
   if (blockIdx.y == 0)
     grid_build_body<false, true>(from, g, blockIdx.x, hist, cursor, wsum);
   else
@@ -1006,7 +1042,7 @@ __global__ __launch_bounds__(GB_THREADS) void k_link_grid_build(const orbgpu_key
                                                                 int *__restrict__ to_counts, int *__restrict__ cell_start,
                                                                 int *__restrict__ s_idx, uint4 *__restrict__ s_desc,
                                                                 double2 *__restrict__ s_xy) {
-  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64 + 1];
+  __shared__ int hist[GRID_BINS], cursor[GRID_BINS], wsum[GB_THREADS / 64 + 2];
   const int p = blockIdx.x;
   const size_t out = (size_t)p * capacity;
   if (blockIdx.y == 0) {

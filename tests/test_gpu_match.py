@@ -547,3 +547,42 @@ def test_single_window_search_over_the_grid(oracle, n_to, n_from, grid_min):
         assert np.array_equal(gi, omf), env
         assert np.array_equal(gd[omf >= 0], omd[omf >= 0]), env
         ctx.close()
+
+
+def test_grid_build_crowded_bins(oracle, fe):
+    """Bins of thousands of rows (above the rank-counting limit of 4096): keypoints of a 4K image binned by a grid laid
+    over 640 x 480 -- almost everything clamps into the last row / column of cells -- and a tight cluster.  The grid
+    build switches to its linear stable placement; cell contents stay in ascending row order (push_back order)."""
+    import torch
+    from orb_slam3_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+    counts = [20000, 9000, 300]
+    cap = max(counts)
+    xy = np.zeros((len(counts) * cap, 2))
+    ranges = np.zeros((len(counts), 2), np.int32)
+    for r, n in enumerate(counts):
+        ranges[r] = (r * cap, n)
+        if r == 0:
+            pts = rng.uniform((0, 0), (3840, 2160), (n, 2))                 # 4K keypoints, 640 x 480 grid
+        elif r == 1:
+            pts = rng.uniform((100, 100), (640, 480), (n, 2))
+            pts[1000:7000] = rng.uniform((300, 300), (309.9, 309.9), (6000, 2))   # 6000 rows in one cell
+        else:
+            pts = rng.uniform((0, 0), (640, 480), (n, 2))                   # an ordinary range beside the crowded ones
+        xy[r * cap:r * cap + n] = pts
+    dev = torch.device("cuda", 0)
+    d_xy, d_r = torch.from_numpy(xy).to(dev), torch.from_numpy(ranges).to(dev)
+    d_cs = torch.full((len(counts), 3073), -5, dtype=torch.int32, device=dev)
+    d_it = torch.full((len(counts), cap), -5, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    rc = lib.orbgpu_grid_build_device(fe.handle, d_xy.data_ptr(), d_r.data_ptr(), len(counts), cap, 640.0, 480.0,
+                                      d_cs.data_ptr(), d_it.data_ptr())
+    assert rc == 0, lib.orbgpu_last_error(fe.handle)
+    assert lib.orbgpu_synchronize(fe.handle) == 0
+    cs, it = d_cs.cpu().numpy(), d_it.cpu().numpy()
+    for r, n in enumerate(counts):
+        ocs, oit = oracle.assign_features_to_grid(xy[r * cap:r * cap + n], 640.0, 480.0)
+        same = np.array_equal(cs[r], ocs) and np.array_equal(it[r, :n], oit)
+        assert same, r
+    assert np.diff(cs[0]).max() > 4096 and np.diff(cs[1]).max() >= 6000

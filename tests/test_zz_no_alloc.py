@@ -68,3 +68,41 @@ def test_noalloc_bruteforce_matches_allocating_entry_point(oracle):
                                                     di.data_ptr(), dd.data_ptr())
     assert rc == _lib.E_CAPACITY
     fe.close()
+
+
+def test_noalloc_entry_point_allocates_nothing():
+    """A fresh context whose growable match scratch is still at its initial 1 MiB: the no-alloc entry point runs FIRST, on
+    a problem that needs several MiB of scratch, between two hipMemGetInfo readings that must agree (a call routed through
+    the context's growable buffer would have had to hipMalloc); only then the allocating entry point, for the comparison
+    (and that one does take device memory)."""
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    n_to, n_from = 30000, 400000            # claims 3.2 MB + partials: far above the context's initial 1 MiB
+    frm = synth.descriptors(77, n_from)
+    to = synth.descriptors(78, n_to, planted_from=frm[:5000], planted_frac=0.4, max_flips=50)
+    dt, df = torch.from_numpy(to).to(dev), torch.from_numpy(frm).to(dev)
+    outs = [(torch.full((n_to,), 7, dtype=torch.int32, device=dev), torch.full((n_to,), 7, dtype=torch.int32, device=dev))
+            for _ in range(2)]
+    fe = ORBFeatureExtractor(640, 480, 1.2, 8, 20, 7, max_features=1000)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    rc = lib.orbgpu_match_bruteforce_noalloc_device(fe.handle, dt.data_ptr(), n_to, df.data_ptr(), n_from, 50, 0.9,
+                                                    outs[0][0].data_ptr(), outs[0][1].data_ptr())
+    assert rc == 0, lib.orbgpu_last_error(fe.handle)
+    assert lib.orbgpu_synchronize(fe.handle) == 0
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free1 == free0, "the no-alloc entry point changed the device's free memory"
+    rc = lib.orbgpu_match_bruteforce_device(fe.handle, dt.data_ptr(), n_to, df.data_ptr(), n_from, 50, 0.9,
+                                            outs[1][0].data_ptr(), outs[1][1].data_ptr())
+    assert rc == 0, lib.orbgpu_last_error(fe.handle)
+    assert lib.orbgpu_synchronize(fe.handle) == 0
+    free2, _ = torch.cuda.mem_get_info(dev)
+    assert free2 < free1, "the allocating entry point was expected to grow the context's scratch"
+    gi, ri = outs[0][0].cpu().numpy(), outs[1][0].cpu().numpy()
+    assert np.array_equal(gi, ri) and (ri >= 0).sum() > 1000
+    sel = ri >= 0
+    assert np.array_equal(outs[0][1].cpu().numpy()[sel], outs[1][1].cpu().numpy()[sel])
+    fe.close()
