@@ -378,12 +378,25 @@ def main():
                 legs[leg]["source"] = "64 procedural frames in pinned host memory, frame i = pool[i % 64]; every frame crosses PCIe"
                 kf_result, kf_runner = res, runner
             del runner
-        # all-pairs over the keyframes of the PCIe leg's result
+        # all-pairs over the keyframes of the PCIe leg's result: the popcount kernel (the contract path, the figures below),
+        # then the same call on the exploratory i8 matrix-core engine, asserted identical
         barrier()
         t1 = time.perf_counter()
         nm_kf, _off = kf_runner.match_keyframes(kf_result)
         barrier()
         ap_s = time.perf_counter() - t1
+        check(lib.orbgpu_set_bruteforce_engine(fe.handle, _lib.ENGINE_MFMA_I8))
+        barrier()
+        t1 = time.perf_counter()
+        nm_mf, _ = kf_runner.match_keyframes(kf_result)
+        barrier()
+        ap_mf_s = time.perf_counter() - t1
+        check(lib.orbgpu_set_bruteforce_engine(fe.handle, _lib.ENGINE_POPCOUNT))
+        assert torch.equal(nm_kf, nm_mf), "the MFMA all-pairs engine differs from the popcount engine"
+        tmf = torch.tensor([ap_mf_s], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmf, op=dist.ReduceOp.MAX)
+        ap_mf_s = float(tmf.item())
         ta = torch.tensor([ap_s], dtype=torch.float64, device=dev)
         kn = kf_result.kf_n.to(torch.float64)
         tot, sq2 = kn.sum().reshape(1), (kn ** 2).sum().reshape(1)
@@ -403,7 +416,12 @@ def main():
                                           "matches_rank0": int(nm_kf.sum().item()),
                                           "exchange": "all_gather_into_tensor of descriptors + float angles (36 B per keypoint)"
                                                       if world > 1 else "none (1 rank)"},
+                    "keyframe_allpairs_mfma_i8_exploration": {"seconds": round(ap_mf_s, 4),
+                                                              "descriptor_pairs_per_s": round(dpairs / ap_mf_s, 1),
+                                                              "speedup_over_popcount": round(float(ta.item()) / ap_mf_s, 2),
+                                                              "identical_to_popcount_results": True},
                     "end_to_end_seconds": round(legs["pcie_inclusive"]["seconds"] + float(ta.item()), 4),
+                    "end_to_end_seconds_with_mfma_engine": round(legs["pcie_inclusive"]["seconds"] + ap_mf_s, 4),
                     "links_mean_rank0": round(float(kf_result.n_links.mean()), 1),
                     "keypoints_mean_rank0": round(float(kf_result.n_keypoints.mean()), 1)}
         del kf_result, nm_kf, pooled
@@ -578,6 +596,9 @@ def main():
     # ---- BASELINE.json configs[2]: large images, extraction throughput vs the HBM roofline (informational) -------
     large = {}
     if not args.no_large and world == 1 and headline:
+        # a process maps its streams onto 4 hardware queues: the headline context gives its side streams back (they
+        # come back on demand) before the large-image contexts create theirs
+        check(lib.orbgpu_trim(fe.handle))
         for (lw, lh, lb) in ((1920, 1080, 64), (3840, 2160, 32)):
             lnf = 5000
             lfe = ORBFeatureExtractor(lw, lh, 1.2, 8, 20, 7, device=local_rank, max_batch=lb, max_features=lnf)

@@ -168,10 +168,13 @@ int orbgpu_match_bruteforce_device(orbgpu_ctx *ctx, const uint8_t *d_to_desc, in
                                    const uint8_t *d_from_desc, int32_t n_from, uint32_t threshold, double ratio,
                                    int32_t *d_from_idx_per_to, uint32_t *d_dist);
 
-/* No counterpart in the reference; EXPLORATORY.  Selects how orbgpu_match_bruteforce[_device] evaluates the distances:
+/* No counterpart in the reference; EXPLORATORY.  Selects how the matchers WITHOUT a candidate restriction --
+ * orbgpu_match_bruteforce[_device] and orbgpu_match_allpairs[_angles]_device -- evaluate the distances:
  * ORBGPU_ENGINE_POPCOUNT (default, the contract path: XOR + v_bcnt per pair on the vector ALU) or ORBGPU_ENGINE_MFMA_I8
  * (descriptor bits expanded to +1 / -1 bytes, dot = 256 - 2 * distance exactly, on the i8 matrix cores; candidates above
- * the threshold are dropped a tile at a time).  Same results bit for bit; windowed / grouped matchers are not affected. */
+ * the threshold are dropped a tile at a time).  Same results bit for bit; windowed / grouped matchers are not affected
+ * (few candidates per row: nothing dense to contract), nor are brute-force calls of at most 4 Mi pairs.  With the MFMA
+ * engine orbgpu_match_allpairs*_device takes at most 2880 keypoints per keyframe instead of 4080. */
 #define ORBGPU_ENGINE_POPCOUNT 0
 #define ORBGPU_ENGINE_MFMA_I8 1
 int orbgpu_set_bruteforce_engine(orbgpu_ctx *ctx, int32_t engine);

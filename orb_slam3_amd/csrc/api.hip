@@ -1837,7 +1837,10 @@ static int match_allpairs_locked(orbgpu_ctx *ctx, const void *d_ang_rows, const 
     return fail(ctx, ORBGPU_E_INVALID, "check_orientation needs the keypoint (or angle) arrays of both sets");
   // dynamic LDS plus the kernel's static __shared__ (rotation histogram, counters: < 256 B) must fit the 64 KB a
   // workgroup gets without raising the limit
-  if (allpairs_lds_bytes(capacity) + 256 > 64 * 1024) return fail(ctx, ORBGPU_E_CAPACITY, "capacity above 4080 keypoints per keyframe");
+  // (the matrix-core engine holds another 18 KB of static LDS: its staging buffers and expansion table)
+  if (allpairs_lds_bytes(capacity) + (ctx->bruteforce_mfma ? 19 * 1024 : 256) > 64 * 1024)
+    return fail(ctx, ORBGPU_E_CAPACITY, ctx->bruteforce_mfma ? "capacity above 2880 keypoints per keyframe with the MFMA engine"
+                                                             : "capacity above 4080 keypoints per keyframe");
   if ((uint64_t)n_cols * (uint64_t)((n_rows + 7) & ~7) >= (1ull << 31)) return fail(ctx, ORBGPU_E_INVALID, "too many pairs for one call");
   HIP_TRY(hipSetDevice(ctx->device));
   launch_match_allpairs(ctx, d_ang_rows, d_desc_rows, d_n_rows, n_rows, d_ang_cols, ang_stride, d_desc_cols, d_n_cols, n_cols,

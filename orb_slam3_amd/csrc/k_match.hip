@@ -1488,6 +1488,146 @@ __global__ __launch_bounds__(256) void k_allpairs(const char *__restrict__ ang_r
 }
 
 // ------------------------------------------------------------------------------------------------
+// EXPLORATORY twin of k_allpairs on the i8 matrix cores (orbgpu_set_bruteforce_engine; the popcount kernel above stays
+// the default and the contract path): the scan of k_snn_mfma -- 'to' rows expanded once into the B operand (4 waves x
+// MF_T tiles of 32 = 512 rows per turn), the keyframe's 'from' rows streamed through LDS 32 at a time as +1 / -1 bytes,
+// tiles without a pair inside the threshold dropped after an 8-instruction maximum -- followed by k_allpairs' own tail:
+// ratio / threshold, per-'from' claims and uniqueness in LDS, rotation histogram, count.  A keyframe of more than 512
+// keypoints takes further turns over the 'from' rows.  Same results bit for bit (tests/test_gpu_allpairs.py runs both).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_allpairs_mfma(
+    const char *__restrict__ ang_rows, const uint8_t *__restrict__ desc_rows, const int *__restrict__ n_rows_kp, int n_rows,
+    const char *__restrict__ ang_cols, int ang_stride, const uint8_t *__restrict__ desc_cols,
+    const int *__restrict__ n_cols_kp, int n_cols, int capacity, int row_offset, unsigned threshold, double ratio,
+    int check_orientation, int *__restrict__ n_matches, int *__restrict__ match_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ap_lds[];
+  unsigned long long *claim = reinterpret_cast<unsigned long long *>(ap_lds);  // [capacity] per 'from'
+  int *mj = reinterpret_cast<int *>(claim + capacity);                        // [capacity] per 'to': from index or -1
+  unsigned *md = reinterpret_cast<unsigned *>(mj + capacity);                 // [capacity] per 'to': distance
+  __shared__ __attribute__((aligned(16))) unsigned abuf[2][8 * 2 * 32 * 4];   // [buffer][m][h][row][4 dwords]
+  __shared__ __attribute__((aligned(8))) uint2 lut[256];                      // byte -> its 8 bits as +1 / -1 bytes
+  __shared__ int total;
+  int c, r;
+  if (!xcd_item_frame(n_cols, n_rows, c, r)) return;
+  int *out_n = n_matches + (size_t)r * n_cols + c;
+  int *out_m = match_out ? match_out + ((size_t)r * n_cols + c) * capacity : nullptr;
+  const int n_to = usable_count(n_rows_kp[r], capacity), n_from = usable_count(n_cols_kp[c], capacity);
+  if ((row_offset >= 0 && row_offset + r == c) || n_to == 0 || n_from == 0) {  // a keyframe is not matched with itself
+    if (threadIdx.x == 0) *out_n = 0;
+    if (out_m)
+      for (int i = threadIdx.x; i < capacity; i += 256) out_m[i] = -1;
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  for (int j = tid; j < n_from; j += 256) claim[j] = ~0ull;
+  if (tid == 0) total = 0;
+  lut[tid] = make_uint2(expand_pm1(tid, 0), expand_pm1(tid, 1));
+  const unsigned *__restrict__ td = reinterpret_cast<const unsigned *>(desc_rows + (size_t)r * capacity * 32);
+  const unsigned *__restrict__ fd = reinterpret_cast<const unsigned *>(desc_cols + (size_t)c * capacity * 32);
+  const int dmin = 256 - 2 * (int)threshold;  // dot >= dmin  <=>  distance <= threshold
+  const int sr = tid & 31, sm = tid >> 5;     // staging: dword sm of 'from' row sr of the step
+  auto load_raw = [&](int jb) {
+    const int j = jb + sr;
+    return j < n_from ? fd[(size_t)j * 8 + sm] : 0u;
+  };
+  auto store_exp = [&](int buf, unsigned w) {
+    const uint2 e0 = lut[w & 255u], e1 = lut[(w >> 8) & 255u], e2 = lut[(w >> 16) & 255u], e3 = lut[w >> 24];
+    *reinterpret_cast<uint4 *>(&abuf[buf][((sm * 2 + 0) * 32 + sr) * 4]) = make_uint4(e0.x, e0.y, e1.x, e1.y);
+    *reinterpret_cast<uint4 *>(&abuf[buf][((sm * 2 + 1) * 32 + sr) * 4]) = make_uint4(e2.x, e2.y, e3.x, e3.y);
+  };
+  __syncthreads();  // lut, claims
+  for (int tb = 0; tb < n_to; tb += 4 * MF_T * 32) {  // turns of 512 'to' rows
+    const int to0 = tb + wv * (MF_T * 32);
+    v4i bfrag[MF_T][8];
+#pragma unroll
+    for (int t = 0; t < MF_T; t++) {
+      const int row = min(to0 + t * 32 + col, n_to - 1);
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const unsigned w = td[(size_t)row * 8 + m] >> (16 * h);
+        bfrag[t][m] = v4i{(int)expand_pm1(w, 0), (int)expand_pm1(w, 1), (int)expand_pm1(w, 2), (int)expand_pm1(w, 3)};
+      }
+    }
+    unsigned best[MF_T], second[MF_T];
+#pragma unroll
+    for (int t = 0; t < MF_T; t++) best[t] = second[t] = KEY_NONE;
+    store_exp(0, load_raw(0));
+    __syncthreads();
+    int buf = 0;
+    for (int jb = 0; jb < n_from; jb += 32, buf ^= 1) {
+      const bool more = jb + 32 < n_from;
+      unsigned raw = 0;
+      if (more) raw = load_raw(jb + 32);
+      v16i acc[MF_T];
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const uint4 av = *reinterpret_cast<const uint4 *>(&abuf[buf][((m * 2 + h) * 32 + col) * 4]);
+        const v4i af = v4i{(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+#pragma unroll
+        for (int t = 0; t < MF_T; t++) {
+          if (m == 0) acc[t] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bfrag[t][m], acc[t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < MF_T; t++) {
+        int mx = acc[t][0];
+#pragma unroll
+        for (int q = 1; q < 16; q++) mx = max(mx, acc[t][q]);
+        if (__ballot(mx >= dmin)) {
+          const unsigned cb = (1u << 30) + (unsigned)(jb + 4 * h);
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const int roff = (q & 3) + 8 * (q >> 2);  // C/D layout: row = (reg & 3) + 8 (reg >> 2) + 4 h
+            unsigned key = (unsigned)__mul24(acc[t][q], -(1 << 22)) + cb + (unsigned)roff;
+            key = (key & ((1u << IDX_BITS) - 1u)) < (unsigned)n_from ? key : KEY_NONE;  // rows staged as zero bytes
+            second[t] = umed3(best[t], key, second[t]);
+            best[t] = min(best[t], key);
+          }
+        }
+      }
+      if (more) store_exp(buf ^ 1, raw);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < MF_T; t++) {
+      merge_keys(best[t], second[t], __shfl_xor(best[t], 32), __shfl_xor(second[t], 32));
+      const int row = to0 + t * 32 + col;
+      if (h == 0 && row < n_to) {
+        unsigned d = 0;
+        const int jm = snn_accept(best[t], second[t], threshold, ratio, d);
+        mj[row] = jm;
+        md[row] = d;
+        if (jm >= 0) atomicMin(&claim[jm], ((unsigned long long)d << 32) | (unsigned)row);
+      }
+    }
+  }
+  __syncthreads();
+  // uniqueness (second_nearest_neighbor_matcher.hpp:57-70): a 'from' keeps its smallest distance, earliest 'to'
+  int cnt = 0;
+  for (int i = tid; i < n_to; i += 256) {
+    const int jm = mj[i];
+    if (jm >= 0) {
+      if (claim[jm] != (((unsigned long long)md[i] << 32) | (unsigned)i)) mj[i] = -1;
+      else cnt++;
+    }
+  }
+  if (cnt) atomicAdd(&total, cnt);
+  __syncthreads();
+  if (check_orientation) {
+    const char *kt = ang_rows + (size_t)r * capacity * ang_stride, *kf = ang_cols + (size_t)c * capacity * ang_stride;
+    rotation_filter_block(
+        n_to, mj, [&](int i) { return *reinterpret_cast<const float *>(kt + (size_t)i * ang_stride); },
+        [&](int jj) { return *reinterpret_cast<const float *>(kf + (size_t)jj * ang_stride); }, nullptr, out_n);
+    __syncthreads();
+  } else if (tid == 0) {
+    *out_n = total;
+  }
+  if (out_m)
+    for (int i = tid; i < capacity; i += 256) out_m[i] = i < n_to ? mj[i] : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // popcount ceiling: the inner loop of snn_scan with the 'from' words synthesised in SGPRs (no memory)
 __global__ __launch_bounds__(256) void k_popcount_peak(unsigned *sink, int iters) {
   unsigned t[8];
@@ -1846,10 +1986,16 @@ void launch_match_allpairs(const orbgpu_ctx *c, const void *d_ang_rows, const ui
                            int check_orientation, int *d_n_matches, int *d_match) {
   const unsigned th = std::min(threshold, 256u);
   dim3 grid((unsigned)n_cols * (unsigned)xcd_frames(n_rows));
-  hipLaunchKernelGGL(k_allpairs, grid, dim3(256), allpairs_lds_bytes(capacity), c->stream,
-                     reinterpret_cast<const char *>(d_ang_rows), d_desc_rows, d_n_rows, n_rows,
-                     reinterpret_cast<const char *>(d_ang_cols), ang_stride, d_desc_cols, d_n_cols, n_cols, capacity,
-                     row_offset, th, ratio, check_orientation, d_n_matches, d_match);
+  if (c->bruteforce_mfma)
+    hipLaunchKernelGGL(k_allpairs_mfma, grid, dim3(256), allpairs_lds_bytes(capacity), c->stream,
+                       reinterpret_cast<const char *>(d_ang_rows), d_desc_rows, d_n_rows, n_rows,
+                       reinterpret_cast<const char *>(d_ang_cols), ang_stride, d_desc_cols, d_n_cols, n_cols, capacity,
+                       row_offset, th, ratio, check_orientation, d_n_matches, d_match);
+  else
+    hipLaunchKernelGGL(k_allpairs, grid, dim3(256), allpairs_lds_bytes(capacity), c->stream,
+                       reinterpret_cast<const char *>(d_ang_rows), d_desc_rows, d_n_rows, n_rows,
+                       reinterpret_cast<const char *>(d_ang_cols), ang_stride, d_desc_cols, d_n_cols, n_cols, capacity,
+                       row_offset, th, ratio, check_orientation, d_n_matches, d_match);
 }
 
 void launch_rotation_filter(const orbgpu_ctx *c, const float *d_ang_to, int n_to, const float *d_ang_from, int *d_match,

@@ -34,13 +34,18 @@ def _sets(seed, n_kf, cap, n_min, n_max):
     return kp, desc, n
 
 
+@pytest.mark.parametrize("engine", ["popcount", "mfma_i8"])
 @pytest.mark.parametrize("cap,n_min,n_max,n_kf", [(256, 0, 200, 5), (1024, 900, 1024, 3), (1536, 1100, 1536, 2)])
-def test_allpairs_matches_oracle(oracle, cap, n_min, n_max, n_kf):
+def test_allpairs_matches_oracle(oracle, cap, n_min, n_max, n_kf, engine):
+    """both engines (orbgpu_set_bruteforce_engine): the popcount kernel -- the default and the contract path -- and the
+    exploratory i8 matrix-core kernel (k_allpairs_mfma), which takes a second and third turn over the 'from' rows for
+    keyframes of more than 512 / 1024 keypoints"""
     import torch
     from orb_slam3_amd import _lib
     from orb_slam3_amd.features import ORBFeatureExtractor
     lib = _lib.load()
     fe = ORBFeatureExtractor(160, 120, 1.2, 3, 20, 7, max_features=100)
+    assert lib.orbgpu_set_bruteforce_engine(fe.handle, _lib.ENGINE_MFMA_I8 if engine == "mfma_i8" else _lib.ENGINE_POPCOUNT) == 0
     kp, desc, n = _sets(5 + cap, n_kf, cap, n_min, n_max)
     if n_min == 0:
         n[1] = 0   # an empty keyframe
