@@ -237,6 +237,15 @@ float elapsed(hipEvent_t a, hipEvent_t b) {
 // streams forked from it (and joined back into it at the end): every kernel here is bound by instruction issue or by
 // latency, never by HBM, so the dependent, latency-bound stages of one slice (quadtree rounds, orientation ->
 // descriptor chains, small pyramid levels) fill issue slots that the instruction-bound stages of another leave.
+// Whether an extract call of `feature_count` keypoints per frame blurs per keypoint (k_patch_describe) instead of per
+// frame: when the keypoints' 43 x 43 patches cover well under the pyramid's pixels.  ORBGPU_PATCH_BLUR=0 / 1 overrides.
+bool patch_mode(const orbgpu_ctx *ctx, int feature_count) {
+  if (ctx->patch_blur_forced >= 0) return ctx->patch_blur_forced != 0;
+  long long P = 0;
+  for (int l = 0; l < ctx->geom.levels; l++) P += (long long)ctx->geom.lv[l].w * ctx->geom.lv[l].h;
+  return (double)feature_count * 43.0 * 43.0 < ORBGPU_PATCH_BLUR_RATIO * (double)P;
+}
+
 // capture: the call is being recorded into a hipGraph (single-frame host path): no timing events, no event-ring bookkeeping
 int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                  int *d_n_out, bool capture = false) {
@@ -281,13 +290,17 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     if (early) HIP_TRY(hipStreamWaitEvent(fs.stream, sev[4], 0));  // the quadtree needs every level's cells
     // the blur's fork point: the FAST kernel's end event when it has just been recorded (one event between two kernels
     // of the critical path instead of two)
+    // patch mode (large images, few keypoints per pixel): no full-frame blur at all -- one kernel behind the quadtree takes
+    // the orientation, blurs the keypoint's own 43 x 43 patch and runs the tests (k_patch_describe)
+    const bool patch = patch_mode(ctx, feature_count);
+    ctx->last_patch_mode = patch;
     hipEvent_t fork_ev = timed_fast ? ev[2] : sev[0];
-    if (fork_ev == sev[0]) HIP_TRY(hipEventRecord(sev[0], fs.stream));
+    if (fork_ev == sev[0] && !patch) HIP_TRY(hipEventRecord(sev[0], fs.stream));
     // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
     // dependent rounds in levels x frames workgroups and leaves most of the chip idle
     // (enqueued after the quadtree so that the quadtree's workgroups are placed first and the blur fills the rest)
     launch_quadtree_presort(ctx, fs, budget);
-    if (ctx->qt_ps_active && ctx->qt_ps_blur_late) {  // the blur starts beside the quadtree kernel, behind the presort
+    if (ctx->qt_ps_active && ctx->qt_ps_blur_late && !patch) {  // the blur starts beside the quadtree kernel, behind the presort
       fork_ev = sev[0];
       HIP_TRY(hipEventRecord(sev[0], fs.stream));
     }
@@ -298,16 +311,26 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
       return fail(ctx, ORBGPU_E_CAPACITY, "feature budget too large for the quadtree kernel's LDS");
     }
     if (timed) HIP_TRY(hipEventRecord(ev[4], fs.stream));
-    launch_orient(ctx, fs);  // IC_Angle needs the unblurred levels only: beside the blur, behind the quadtree
-    if (timed) HIP_TRY(hipEventRecord(ev[3], fs.stream));
-    HIP_TRY(hipStreamWaitEvent(fb.stream, fork_ev, 0));
-    if (timed) HIP_TRY(hipEventRecord(ev[7], fb.stream));
-    launch_blur(ctx, fb);
-    if (timed) HIP_TRY(hipEventRecord(ev[8], fb.stream));
-    HIP_TRY(hipEventRecord(sev[1], fb.stream));
-    HIP_TRY(hipStreamWaitEvent(fs.stream, sev[1], 0));
-    if (timed) HIP_TRY(hipEventRecord(ev[5], fs.stream));
-    launch_describe(ctx, fs, d_kp, d_desc, capacity, d_n_out);
+    if (patch) {
+      if (timed) {  // the stage timers report orientation and blur as 0: both live inside the descriptor stage
+        HIP_TRY(hipEventRecord(ev[3], fs.stream));
+        HIP_TRY(hipEventRecord(ev[7], fs.stream));
+        HIP_TRY(hipEventRecord(ev[8], fs.stream));
+        HIP_TRY(hipEventRecord(ev[5], fs.stream));
+      }
+      launch_patch_describe(ctx, fs, d_kp, d_desc, capacity, d_n_out);
+    } else {
+      launch_orient(ctx, fs);  // IC_Angle needs the unblurred levels only: beside the blur, behind the quadtree
+      if (timed) HIP_TRY(hipEventRecord(ev[3], fs.stream));
+      HIP_TRY(hipStreamWaitEvent(fb.stream, fork_ev, 0));
+      if (timed) HIP_TRY(hipEventRecord(ev[7], fb.stream));
+      launch_blur(ctx, fb);
+      if (timed) HIP_TRY(hipEventRecord(ev[8], fb.stream));
+      HIP_TRY(hipEventRecord(sev[1], fb.stream));
+      HIP_TRY(hipStreamWaitEvent(fs.stream, sev[1], 0));
+      if (timed) HIP_TRY(hipEventRecord(ev[5], fs.stream));
+      launch_describe(ctx, fs, d_kp, d_desc, capacity, d_n_out);
+    }
     if (timed) HIP_TRY(hipEventRecord(ev[6], fs.stream));
     if (s > 0) {  // join
       HIP_TRY(hipEventRecord(sev[2], fs.stream));
@@ -532,6 +555,8 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     ctx->window_grid_forced = wg != nullptr;
     const char *ls = std::getenv("ORBGPU_LINK_SCAN");  // 1: large-capacity frame links by the plain scan, not the grid
     ctx->link_plain_scan = ls && ls[0] == '1';
+    const char *pb = std::getenv("ORBGPU_PATCH_BLUR");  // 0 / 1: full-frame blur / per-keypoint patch blur whatever the size
+    ctx->patch_blur_forced = pb ? (pb[0] == '1' ? 1 : 0) : -1;
     const char *ng = std::getenv("ORBGPU_NO_GRAPH");  // 1: single-frame host calls enqueue eagerly instead of replaying a hipGraph
     ctx->graph_single_frame = !(ng && ng[0] == '1');
     const char *o = std::getenv("ORBGPU_SLICES");  // tuning aid: slices per batch, 0 / unset = automatic
@@ -963,6 +988,12 @@ int orbgpu_debug_dump(orbgpu_ctx *ctx, int32_t frame, uint8_t *pyramid, uint8_t 
     if (!ctx->d_score) HIP_TRY(dmalloc(&ctx->d_score, (size_t)g.frame_bytes + 256));
     HIP_TRY(hipMemsetAsync(ctx->d_score, 0, g.frame_bytes, ctx->stream));
     launch_fast_cells(ctx, FrameSlice{frame, 1, ctx->stream}, ctx->d_score);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  if (blurred && ctx->last_patch_mode) {
+    // the last call blurred per keypoint: the full-frame blur of that frame is produced here, for the stage tests
+    launch_blur(ctx, FrameSlice{frame, 1, ctx->stream});
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }

@@ -8,6 +8,7 @@
 
 #include "orbgpu_internal.h"
 #include "tile_stage.hpp"
+#include "blur_math.hpp"
 
 namespace {
 
@@ -78,6 +79,41 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   if (x < 0) a = __fsub_rn(180.f, a);
   if (y < 0) a = __fsub_rn(360.f, a);
   return a;
+}
+
+// cos / sin of the descriptor rotation: the reference evaluates them on float(angle * pi / 180) and keeps floats
+// (orb_feature_extractor.cpp:123-124); the oracle takes glibc's double cos / sin rounded to float.
+// The argument lies in [0, 2 pi], so a two-constant Cody-Waite reduction and the fdlibm kernels are enough, in explicit
+// IEEE operations.  tools/sincos_check.c compares this very sequence with glibc for EVERY float in [0, 6.4] (1.09e9
+// values): both results round to the same float each time.  About a quarter of the device libm's sincos, which also
+// carries the huge-argument reduction and its scratch.
+__device__ __forceinline__ void sincos_short(double x, double &sn, double &cs) {
+  const double TWO_OVER_PI = 0.63661977236758134308, PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+  const double k = rint(__dmul_rn(x, TWO_OVER_PI));
+  double r = __fma_rn(-k, PIO2_HI, x);
+  r = __fma_rn(-k, PIO2_LO, r);
+  const double z = __dmul_rn(r, r);
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double ps = __fma_rn(z, S6, S5);
+  ps = __fma_rn(z, ps, S4);
+  ps = __fma_rn(z, ps, S3);
+  ps = __fma_rn(z, ps, S2);
+  ps = __fma_rn(z, ps, S1);
+  const double s = __fma_rn(__dmul_rn(r, z), ps, r);
+  double pc = __fma_rn(z, C6, C5);
+  pc = __fma_rn(z, pc, C4);
+  pc = __fma_rn(z, pc, C3);
+  pc = __fma_rn(z, pc, C2);
+  pc = __fma_rn(z, pc, C1);
+  const double hz = __dmul_rn(0.5, z);
+  const double w = __dsub_rn(1.0, hz);
+  const double c = __dadd_rn(w, __dadd_rn(__dsub_rn(__dsub_rn(1.0, w), hz), __dmul_rn(__dmul_rn(z, z), pc)));
+  const int q = (int)k & 3;
+  sn = q == 0 ? s : q == 1 ? c : q == 2 ? -s : -c;
+  cs = q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
 }
 
 constexpr int PR = 18;              // patch radius staged for the descriptor: the pattern's points lie within 18.385 px
@@ -263,7 +299,7 @@ __global__ __launch_bounds__(64 * KPB) void k_describe(const uint8_t *__restrict
     s_cs[threadIdx.x][1] = sinf(ang);
 #else
     double sn, cs;
-    sincos((double)ang, &sn, &cs);  // one shared range reduction; same kernels as sin() / cos()
+    sincos_short((double)ang, sn, cs);
     s_cs[threadIdx.x][0] = (float)cs;
     s_cs[threadIdx.x][1] = (float)sn;
 #endif
@@ -326,7 +362,271 @@ __global__ __launch_bounds__(64 * KPB) void k_describe(const uint8_t *__restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_patch_describe: orientation + Gaussian blur + rotated BRIEF of a keypoint from ONE unblurred 43 x 43 patch -- for
+// contexts whose keypoints' patches cover far fewer pixels than the pyramid (1080p / 4K frames at 5000 keypoints: the
+// full-frame blur writes and k_describe re-reads a blurred pyramid of which the descriptors touch a fifth).  No blurred
+// slab, no blur kernel, no join of a second stream; the quadtree kernel is followed by this one alone.
+//   cv::GaussianBlur applies its 7 x 7 kernel without intermediate rounding (the horizontal sums are exact 16-bit
+//   integers, blur_math.hpp), so a blurred pixel is an exact function of its 7 x 7 unblurred neighbourhood: the taps
+//   reach 18 px from the keypoint (PR), their blur 3 px further (QR = 21).  Keypoints sit >= 19 px from the image edge
+//   (EDGE_THRESHOLD), so a patch can reach 2 px beyond it: those keypoints gather their patch byte by byte with
+//   BORDER_REFLECT_101 indices, the others with aligned dword loads straight into LDS.
+// A wave owns FKPW keypoints and works on them alone (no workgroup barrier after the weight table is staged):
+//   gather (all patches in flight) -> IC_Angle on the 31 x 31 disc of each raw patch (k_orient's weight table) -> cos / sin
+//   of the wave's keypoints side by side on as many lanes -> per keypoint: horizontal 7-tap on row pairs (lane = dword of a
+//   pair of rows, neighbours by DPP, k_blur's hblur_px) into (row 2m, row 2m+1) u16 pairs in LDS, vertical 7-tap
+//   (vblur_px) back over the raw patch's core, the 256 tests (k_describe's), the output record.
+constexpr int QR = PR + 3;                 // 21: radius of the raw patch
+constexpr int QW = 2 * QR + 1;             // 43 rows / columns
+constexpr int QDW = 12;                    // aligned dwords per staged row: 43 bytes + up to 3 of misalignment
+constexpr int QPITCH = QDW * 4;            // 48
+constexpr int QRI = 64 / QDW;              // rows per load instruction (5: 60 lanes)
+constexpr int QNI = (QW + QRI - 1) / QRI;  // load instructions per patch (9)
+constexpr int RAW_DW = QNI * QRI * QDW;    // 45 rows of 12 dwords: rows 43, 44 are never loaded (row 43 is read with weight 0)
+constexpr int HB_PAIRS = (QW + 1) / 2;     // 22 row pairs
+constexpr int HB_PITCH = 48;               // dwords (pixels) per row pair
+constexpr int FKPB = 4;                    // waves per workgroup (8: 16 waves per CU instead of 12, same time)
+constexpr int FKPW = 2;                    // keypoints per wave
+constexpr int FKPG = FKPB * FKPW;
+
+__global__ __launch_bounds__(64 * FKPB) void k_patch_describe(const uint8_t *__restrict__ pyr, DeviceGeom g,
+                                                              const short2 *__restrict__ kp_xy,
+                                                              const int *__restrict__ kp_count,
+                                                              float *__restrict__ kp_angle,
+                                                              orbgpu_keypoint *__restrict__ out_kp,
+                                                              uint8_t *__restrict__ out_desc, int capacity,
+                                                              int *__restrict__ out_n, int n_frames, Level0Src lvl0,
+                                                              int *__restrict__ error_flag) {
+  __shared__ uint2 s_tab[4 * OT_STRIDE];
+  __shared__ __attribute__((aligned(16))) unsigned s_raw[FKPG][RAW_DW];
+  __shared__ __attribute__((aligned(16))) unsigned s_hb[FKPB][HB_PAIRS * HB_PITCH];
+  int f, group;
+  if (!xcd_item_frame((g.kps_per_frame + FKPG - 1) / FKPG, n_frames, group, f)) return;
+#pragma unroll
+  for (int i = 0; i < 4 * OT_STRIDE / (64 * FKPB); i++) s_tab[i * 64 * FKPB + threadIdx.x] = c_orient.e[i * 64 * FKPB + threadIdx.x];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int *cnt = kp_count + f * g.levels;
+  // inclusive prefix of the per-level counts, per wave (16 lanes, no barrier)
+  int pre = lane < g.levels ? cnt[lane] : 0;
+#pragma unroll
+  for (int o = 1; o < ORBGPU_MAX_LEVELS; o <<= 1) {
+    const int u = __shfl_up(pre, o);
+    if (lane >= o) pre += u;
+  }
+  const int total = __builtin_amdgcn_readlane(pre, ORBGPU_MAX_LEVELS - 1);
+  if (group == 0 && threadIdx.x == 0) {
+    out_n[f] = total;
+    if (total > capacity) *(volatile int *)error_flag = ORBGPU_ERR_OUT_CAPACITY;  // mapped host memory: a plain store
+  }
+  int slot[FKPW], lv[FKPW], idx[FKPW], cx[FKPW], cy[FKPW], sh[FKPW];
+  bool valid[FKPW];
+  short2 xy[FKPW];
+#pragma unroll
+  for (int h = 0; h < FKPW; h++) {
+    slot[h] = group * FKPG + wave * FKPW + h;
+    lv[h] = __builtin_amdgcn_readfirstlane(level_of(g.kp_offs, slot[h]));
+    idx[h] = slot[h] - g.lv[lv[h]].kp_off;
+    valid[h] = slot[h] < g.kps_per_frame && idx[h] < cnt[lv[h]];
+    xy[h] = make_short2(0, 0);
+    if (valid[h]) xy[h] = kp_xy[(size_t)f * g.kps_per_frame + slot[h]];
+    cx[h] = cy[h] = sh[h] = 0;
+  }
+  // ---- gather the raw patches -------------------------------------------------------------------------------------
+  const int psub = lane / QDW, pdw = lane - psub * QDW;
+#pragma unroll
+  for (int h = 0; h < FKPW; h++) {
+    if (!valid[h]) continue;
+    cx[h] = __builtin_amdgcn_readfirstlane((int)xy[h].x);
+    cy[h] = __builtin_amdgcn_readfirstlane((int)xy[h].y);
+    const LevelGeom &L = g.lv[lv[h]];
+    const uint8_t *src = level_src(pyr, g, lvl0, f, lv[h], L.off);
+    unsigned *R = s_raw[wave * FKPW + h];
+    const bool inside = cx[h] - QR >= 0 && cx[h] + QR <= L.w - 1 && cy[h] - QR >= 0 && cy[h] + QR <= L.h - 1;
+    if (inside) {
+      const int xb = (cx[h] - QR) & ~3;
+      sh[h] = (cx[h] - QR) - xb;
+      // the row's last dword (bytes 44 .. 47) holds patch bytes only when the patch starts at byte 2 or 3 of its first
+      // dword; otherwise it lies wholly beyond the patch (and may lie beyond the image row): not loaded
+      const bool want = lane < QRI * QDW && (pdw < QDW - 1 || sh[h] >= 2);
+      const uint8_t *bsrc = src + (size_t)(cy[h] - QR) * L.pitch + xb;
+      const unsigned poff = (unsigned)(psub * L.pitch + 4 * pdw);
+#pragma unroll
+      for (int k = 0; k < QNI; k++)
+        if (want && QRI * k + psub < QW)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned *>(bsrc + (poff + (unsigned)(QRI * k * L.pitch))),
+                                           R + QRI * QDW * k, 4, 0, 0);
+    } else {
+      // BORDER_REFLECT_101 (cv::GaussianBlur's border, :559): byte by byte, patch column 0 at byte 0 of the staged row
+      uint8_t *R8 = reinterpret_cast<uint8_t *>(R);
+      for (int i = lane; i < QW * QW; i += 64) {
+        const int r = i / QW, c = i - r * QW;
+        int gy = cy[h] - QR + r, gx = cx[h] - QR + c;
+        gy = gy < 0 ? -gy : (gy > L.h - 1 ? 2 * (L.h - 1) - gy : gy);
+        gx = gx < 0 ? -gx : (gx > L.w - 1 ? 2 * (L.w - 1) - gx : gx);
+        R8[r * QPITCH + c] = src[(size_t)gy * L.pitch + gx];
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's patches have landed in LDS
+  __syncthreads();                                             // s_tab (the only workgroup-wide dependency)
+  bool any_valid = false;
+#pragma unroll
+  for (int h = 0; h < FKPW; h++) any_valid |= valid[h];
+  if (total > capacity || !any_valid) return;
+  // ---- IC_Angle on the raw patches (rows 6 .. 36, columns sh + 6 .. sh + 36 of the staged patch) -----------------------
+  const int osub = lane / ODW, oc = lane - osub * ODW;
+  float ang[FKPW];
+#pragma unroll
+  for (int h = 0; h < FKPW; h++) {
+    ang[h] = 0.f;
+    if (!valid[h]) continue;
+    const unsigned *R = s_raw[wave * FKPW + h];
+    const int osh = (sh[h] + (QR - ORB_HALF_PATCH)) & 3, odw = (sh[h] + (QR - ORB_HALF_PATCH)) >> 2;
+    unsigned a10 = 0, si = 0;
+    int m01 = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int row = 7 * k + osub;  // row of the disc; lanes beyond it read weight 0
+      const unsigned px = (lane < 63 && row < ORB_PATCH) ? R[(row + QR - ORB_HALF_PATCH) * QDW + odw + oc] : 0u;
+      const uint2 ow = s_tab[osh * OT_STRIDE + 63 * k + min(lane, 62)];
+      const unsigned rs = __builtin_amdgcn_udot4(px, ow.y, 0u, false);
+      a10 = __builtin_amdgcn_udot4(px, ow.x, a10, false);
+      si += rs;
+      m01 += (row - ORB_HALF_PATCH) * (int)rs;
+    }
+    int m10 = (int)a10 - ORB_HALF_PATCH * (int)si;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      m10 += __shfl_xor(m10, off);
+      m01 += __shfl_xor(m01, off);
+    }
+    ang[h] = fast_atan2_deg((float)m01, (float)m10);
+  }
+  // ---- cos / sin of the wave's keypoints, keypoint h on lane h (float(angle_deg) * (double)(pi / 180) -> float, cos / sin
+  //      evaluated in double and rounded to float) ------------------------------------------------------
+  float my_ang = ang[0];
+#pragma unroll
+  for (int h = 1; h < FKPW; h++) my_ang = lane == h ? ang[h] : my_ang;
+  float my_cos, my_sin;
+  {
+    const double factorPI = 3.14159265358979323846 / 180.;
+    const float a = (float)((double)my_ang * factorPI);
+#ifdef ORBGPU_TRIG_F32
+    my_cos = cosf(a);
+    my_sin = sinf(a);
+#else
+    double sn, cs;
+    sincos_short((double)a, sn, cs);
+    my_cos = (float)cs;
+    my_sin = (float)sn;
+#endif
+  }
+  const float4 *pat = reinterpret_cast<const float4 *>(c_pattern.v);
+  float4 ptn[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) ptn[q] = pat[64 * q + lane];
+  unsigned *HB = s_hb[wave];
+  const int hpl = lane / QDW, hd = lane - hpl * QDW;  // horizontal pass: row pair within a step, dword
+  const bool vodd = lane & 1;                         // vertical pass: the lane's output rows start on a pair's second row
+#pragma unroll  // (a rolled loop would index the per-keypoint registers dynamically: scratch memory)
+  for (int h = 0; h < FKPW; h++) {
+    if (!valid[h]) continue;
+    unsigned *R = s_raw[wave * FKPW + h];
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_cos), h));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sin), h));
+    // ---- horizontal 7-tap, two rows at a time: lane = (row pair, dword); the neighbours' dwords by DPP.  A pair's first
+    //      dword takes its left neighbour from the previous pair's last dword and vice versa: that only reaches output
+    //      bytes 0 .. 2 and 45 .. 47 of a row, outside the 37 columns sh + 3 .. sh + 39 the vertical pass reads
+#pragma unroll
+    for (int p = 0; p < (HB_PAIRS + QRI - 1) / QRI; p++) {
+      const int m = QRI * p + hpl;
+      const bool live = lane < QRI * QDW && m < HB_PAIRS;
+      const int mm = live ? m : 0;
+      const unsigned r0 = R[(2 * mm) * QDW + hd], r1 = R[(2 * mm + 1) * QDW + hd];
+      const unsigned w0[3] = {from_left(r0), r0, from_right(r0)}, w1[3] = {from_left(r1), r1, from_right(r1)};
+      uint4 o;
+      o.x = hblur_px<0>(w0) | (hblur_px<0>(w1) << 16);
+      o.y = hblur_px<1>(w0) | (hblur_px<1>(w1) << 16);
+      o.z = hblur_px<2>(w0) | (hblur_px<2>(w1) << 16);
+      o.w = hblur_px<3>(w0) | (hblur_px<3>(w1) << 16);
+      if (live) *reinterpret_cast<uint4 *>(HB + m * HB_PITCH + 4 * hd) = o;
+    }
+    // ---- vertical 7-tap over the core: output rows 3 .. 39, dwords 0 .. 10, written over the raw patch.  Even lanes take
+    //      the rows whose 7 source rows start on the first row of a pair, odd lanes the others, so a lane's weights never
+    //      change; item j = (64 p + lane) / 2 = (row pair jr, dword d) advances by 32 = 2 * 11 + 10 per step ------------------
+    {
+      int jr = (lane >> 1) / (QDW - 1), d = (lane >> 1) - jr * (QDW - 1);
+#pragma unroll
+      for (int p = 0; p < (2 * ((PW + 1) / 2) * (QDW - 1) + 63) / 64; p++) {
+        const int yr = 2 * jr + (lane & 1);  // output row - 3 = first of its 7 source rows
+        if (yr < PW) {
+          const uint4 A = *reinterpret_cast<const uint4 *>(HB + (jr + 0) * HB_PITCH + 4 * d);
+          const uint4 B = *reinterpret_cast<const uint4 *>(HB + (jr + 1) * HB_PITCH + 4 * d);
+          const uint4 C = *reinterpret_cast<const uint4 *>(HB + (jr + 2) * HB_PITCH + 4 * d);
+          const uint4 D = *reinterpret_cast<const uint4 *>(HB + (jr + 3) * HB_PITCH + 4 * d);
+          const unsigned v0 = vblur_px(A.x, B.x, C.x, D.x, vodd), v1 = vblur_px(A.y, B.y, C.y, D.y, vodd);
+          const unsigned v2 = vblur_px(A.z, B.z, C.z, D.z, vodd), v3 = vblur_px(A.w, B.w, C.w, D.w, vodd);
+          // every accumulator is < 2^24: the result pixel is its byte 2
+          R[(yr + 3) * QDW + d] = __builtin_amdgcn_perm(v1, v0, 0x0c0c0602u) | (__builtin_amdgcn_perm(v3, v2, 0x0c0c0602u) << 16);
+        }
+        d += 10;
+        jr += 2;
+        if (d >= QDW - 1) {
+          d -= QDW - 1;
+          jr++;
+        }
+      }
+    }
+    // ---- rotated BRIEF on the blurred core (computeOrbDescriptor :120-165), as k_describe ----------------------------
+    const int l = lv[h];
+    const int pos = total - 1 - ((l ? __builtin_amdgcn_readlane(pre, max(l - 1, 0)) : 0) + idx[h]);  // reversed packing, App. B.4
+    const uint8_t *P8 = reinterpret_cast<const uint8_t *>(R) + QR * QPITCH + QR + sh[h];
+    unsigned long long bits[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 pt = ptn[q];
+      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+      const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+      const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+      const int t0 = P8[r0 * QPITCH + c0];
+      const int t1 = P8[r1 * QPITCH + c1];
+      bits[q] = __ballot(t0 < t1);
+    }
+    if (lane == 0) {
+      unsigned long long *dd = reinterpret_cast<unsigned long long *>(out_desc + ((size_t)f * capacity + pos) * 32);
+      dd[0] = bits[0]; dd[1] = bits[1]; dd[2] = bits[2]; dd[3] = bits[3];
+      const LevelGeom &L = g.lv[l];
+      orbgpu_keypoint k;
+      k.x = (double)cx[h];
+      k.y = (double)cy[h];
+      if (l != 0) {  // keypoint->pt *= (float)scale_factors_[level], orb_feature_extractor.cpp:568-577
+        k.x *= (double)L.scale_f;
+        k.y *= (double)L.scale_f;
+      }
+      k.angle = ang[h];
+      k.size = L.kp_size;
+      k.level = l;
+      k.reserved = 0;
+      out_kp[(size_t)f * capacity + pos] = k;
+      kp_angle[(size_t)f * g.kps_per_frame + slot[h]] = ang[h];
+    }
+  }
+}
+
 }  // namespace
+
+void launch_patch_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
+                           int *d_n_out) {
+  const DeviceGeom &g = c->geom;
+  dim3 grid((g.kps_per_frame + FKPG - 1) / FKPG * xcd_frames(fs.n));
+  hipLaunchKernelGGL(k_patch_describe, grid, dim3(64 * FKPB), 0, fs.stream, c->d_pyr + (size_t)fs.f0 * g.frame_bytes, g,
+                     c->d_kp_xy + (size_t)fs.f0 * g.kps_per_frame, c->d_kp_count + (size_t)fs.f0 * g.levels,
+                     c->d_kp_angle + (size_t)fs.f0 * g.kps_per_frame, d_kp + (size_t)fs.f0 * capacity,
+                     d_desc + (size_t)fs.f0 * capacity * 32, capacity, d_n_out + fs.f0, fs.n, slice_lvl0(c, fs),
+                     c->d_error_flag);
+}
 
 void launch_orient(const orbgpu_ctx *c, FrameSlice fs) {
   const DeviceGeom &g = c->geom;

@@ -8,6 +8,7 @@
 
 #include "orbgpu_internal.h"
 #include "tile_stage.hpp"
+#include "blur_math.hpp"
 
 namespace {
 
@@ -263,27 +264,7 @@ __global__ __launch_bounds__(256) void k_resize_strips(uint8_t *__restrict__ pyr
 //   horizontal: per pixel the 12-byte window of its dword and two or three v_dot4_u32_u8 against the kernel bytes shifted
 //               to where the pixel's taps fall; two rows are interleaved into (row 2m, row 2m+1) u16 pairs per pixel;
 //   vertical:   four v_dot2_u32_u16 per pixel on those row pairs (weights chosen by the parity of the output row).
-typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
-__device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
-__device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
-
-// horizontal 7-tap of pixel P (0..3) of the middle dword of the 12-byte window {w0,w1,w2}: the pixel's first tap is byte
-// 1 + P of the window, so the 7 taps are spread over two or three ALIGNED dwords; each takes one v_dot4_u32_u8 against
-// the kernel (18 34 48 56 48 34 18) shifted to where its bytes fall -- no byte realignment.  <= 65280
-template <int P>
-__device__ __forceinline__ unsigned hblur_px(const unsigned (&w)[3]) {
-  constexpr unsigned long long K = 18ull | (34ull << 8) | (48ull << 16) | (56ull << 24) | (48ull << 32) | (34ull << 40) |
-                                   (18ull << 48);
-  // byte j of the 12-byte window carries tap j - (1 + P): the kernel as a 96-bit constant shifted left by 1 + P bytes
-  constexpr int SH = 8 * (1 + P);
-  constexpr unsigned K0 = (unsigned)(K << SH), K1 = (unsigned)(SH == 32 ? K : (K >> (32 - SH))),
-                     K2 = (unsigned)(SH == 32 ? (K >> 32) : (K >> (64 - SH)));
-  unsigned acc = 0;
-  if (K0) acc = __builtin_amdgcn_udot4(w[0], K0, acc, false);
-  acc = __builtin_amdgcn_udot4(w[1], K1, acc, false);
-  if (K2) acc = __builtin_amdgcn_udot4(w[2], K2, acc, false);
-  return acc;
-}
+// (hblur_px, the DPP neighbour moves and the packed types: blur_math.hpp)
 
 // ------------------------------------------------------------------------------------------------
 // No LDS: a half-wave (32 lanes) owns a STRIP of up to 30 output dwords x 8 * BS_CH - 6 output rows and walks
@@ -296,12 +277,6 @@ __device__ __forceinline__ unsigned hblur_px(const unsigned (&w)[3]) {
 // Both strips of a wave belong to one level, so the level's geometry and row offsets are scalar.
 constexpr int BS_CH = ORBGPU_BLUR_STRIP_CHUNKS;  // chunks of 8 staged rows
 
-__device__ __forceinline__ unsigned from_left(unsigned v) {   // lane i <- lane i - 1 (wave_shr:1)
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
-}
-__device__ __forceinline__ unsigned from_right(unsigned v) {  // lane i <- lane i + 1 (wave_shl:1)
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
-}
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, DeviceGeom g,
                                                      int n_frames, Level0Src lvl0, const short4 *__restrict__ strips,

@@ -12,6 +12,8 @@
 #include "../../include/orbgpu.h"
 
 #define ORBGPU_EV_SETS 32
+// per-keypoint patch blur when feature_count * 43^2 < RATIO * pyramid pixels (measured: see DESIGN.md, kernel table)
+#define ORBGPU_PATCH_BLUR_RATIO 0.75
 #define ORB_EDGE 19        // EDGE_THRESHOLD, src/features/orb_feature_extractor.h:20
 #define ORB_HALF_PATCH 15  // :18
 #define ORB_PATCH 31       // :19
@@ -177,6 +179,8 @@ struct orbgpu_ctx {
   char *h_stage = nullptr, *h_stage_dev = nullptr, *d_stage = nullptr;
   size_t stage_bytes = 0;
   // one frame per host call (orbgpu_extract): the whole call as one captured graph, results in mapped host memory
+  int patch_blur_forced = -1;          // ORBGPU_PATCH_BLUR: -1 by size (patch_mode), 0 never, 1 always
+  bool last_patch_mode = false;        // the last extract call blurred per keypoint (k_patch_describe): d_blur was not written
   bool graph_single_frame = true;      // ORBGPU_NO_GRAPH=1: eager launches instead
   hipGraphExec_t graph_one = nullptr;  // upload + pipeline of one frame for graph_one_features keypoints
   int graph_one_features = 0;
@@ -225,6 +229,9 @@ int build_resize_strips(const DeviceGeom &g, int level, const XTab *xt, std::vec
 void launch_orient(const orbgpu_ctx *c, FrameSlice fs);
 void launch_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                      int *d_n_out);
+// orientation + patch blur + descriptors in one kernel behind the quadtree (no full-frame blur): large-image contexts
+void launch_patch_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
+                           int *d_n_out);
 void launch_keypoint_geometry(const orbgpu_ctx *c, const orbgpu_camera &cam, const orbgpu_keypoint *d_kp, const int *d_n,
                               int n_frames, int capacity, double *d_undist, double *d_unproj, uint8_t *d_ok);
 void launch_import_images(const orbgpu_ctx *c, const uint8_t *d_imgs, int64_t frame_stride, int stride, int n_frames);

@@ -298,3 +298,36 @@ def test_single_frame_graph_recapture_and_eager(oracle, monkeypatch):
             same = np.array_equal(ft.descriptors, odesc)
             assert same, (no_graph, f, nf)
         fe.close()
+
+
+@pytest.mark.parametrize("w,h,nfeat,levels,seed,scene", [
+    (640, 480, 1000, 8, 71, "rich"),
+    (333, 251, 600, 6, 72, "rich"),        # odd sizes: unaligned rows; small levels where most keypoints sit near a border
+    (160, 120, 400, 3, 73, "noise"),       # nearly every patch reaches beyond the image: the reflected byte-wise gather
+    (1280, 720, 3000, 8, 74, "rich"),
+])
+def test_patch_blur_mode(oracle, monkeypatch, w, h, nfeat, levels, seed, scene):
+    """ORBGPU_PATCH_BLUR=1 forces the per-keypoint path (k_patch_describe: orientation + 7 x 7 blur of the keypoint's own
+    43 x 43 patch + rBRIEF in one kernel, by default only where the patches cover well under the pyramid, e.g. 4K / 5000):
+    keypoints, angles and descriptors against the oracle -- i.e. against the full-frame cv::GaussianBlur with
+    BORDER_REFLECT_101 -- and the blurred levels of the stage dump (produced on demand in this mode) as well."""
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    img = _scene(scene, seed, h, w)
+    p = oracle.params(w, h, levels=levels)
+    okp, odesc, ex = oracle.extract(p, img, nfeat, dump=True)
+    monkeypatch.setenv("ORBGPU_PATCH_BLUR", "1")
+    for max_batch in (1, 2):               # the captured single-frame graph and the eager batch path
+        fe = ORBFeatureExtractor(w, h, 1.2, levels, 20, 7, max_batch=max_batch, max_features=nfeat)
+        ft = Features(w, h)
+        assert fe.Extract(img, ft, nfeat) == 0
+        _kp_equal(ft.keypoints, okp)
+        same = np.array_equal(ft.descriptors, odesc)
+        assert same, max_batch
+        d = fe.debug_dump()
+        g = ex["geometry"]
+        for l, (a, b) in enumerate(zip(_levels(d["blurred"], g), _levels(ex["blurred"], g))):
+            if ex["n_kp"][l]:
+                assert np.array_equal(a, b), f"blur level {l}"
+        fe.close()
+    near = ((okp["x"] / 1.2 ** okp["level"] < 21.5) | (okp["y"] / 1.2 ** okp["level"] < 21.5)).sum()
+    assert near > 0                        # some patches did reach beyond the image

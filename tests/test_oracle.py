@@ -668,3 +668,17 @@ def test_working_grid_lists_the_same_set(oracle):
     cs11, it11 = oracle.assign_features_to_grid(xy11, 640.0, 480.0)
     q = lambda w, l0, l1: oracle.list_features_in_area_grid(xy11, lv11, cs11, it11, 640.0, 480.0, 190.0, 80.0, w, l0, l1)
     assert len(q(10, 0, 2)) == 1 and len(q(10, 1, 2)) == 0 and sorted(q(100, 0, 2).tolist()) == [0, 4]
+
+
+def test_sincos_short_matches_glibc_for_every_float(tmp_path):
+    """k_describe.hip computes the descriptor rotation's cos / sin with a short double sequence (Cody-Waite reduction +
+    fdlibm kernels) instead of the device libm.  tools/sincos_check.c restates that sequence in C, operation for operation,
+    and compares its result ROUNDED TO FLOAT with glibc's -- what the oracle uses -- for every float in [0, 6.4]
+    (1,087,163,598 values, every angle the extractor can produce): no mismatch."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    exe = tmp_path / "sincos_check"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", str(root / "tools" / "sincos_check.c"), "-o", str(exe), "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600).stdout
+    assert "floats checked: 1087163598  sin mismatches 0  cos mismatches 0" in out, out

@@ -1,8 +1,6 @@
 #!/bin/bash
-# parity of the large-image batches + their bench section.  Usage: tools/quick_large.sh [env assignments...]
+# bench of the headline + large-image sections only.  Usage: tools/quick_large_bench.sh [env assignments...]
 set -o pipefail
-timeout -k 10 400 env "$@" python -u -m pytest tests/test_gpu_headline.py tests/test_gpu_extract.py tests/test_gpu_batch.py -m gpu -x -q --tb=short --timeout 240 --timeout-method thread -k "not bench_two_ranks and not bruteforce" > gpurun_out/ql_t.log 2>&1 || { tail -30 gpurun_out/ql_t.log; exit 1; }
-tail -1 gpurun_out/ql_t.log
 timeout -k 10 200 env "$@" python bench.py --no-cpu-baseline --no-bruteforce --no-database --no-allpairs --no-projection --no-sequence --no-host-path --steps 10 --warmup 3 > gpurun_out/ql_b.json 2> gpurun_out/ql_b.err || { tail gpurun_out/ql_b.err; exit 1; }
 python3 - <<'P'
 import json
