@@ -19,6 +19,24 @@ int fail(orbgpu_ctx *ctx, int code, const std::string &msg) {
   return code;
 }
 
+const char *orbgpu_tune(const char *key) {
+  static thread_local std::string value;
+  const char *all = std::getenv("ORBGPU_TUNE");
+  if (!all || !key) return nullptr;
+  const size_t klen = std::strlen(key);
+  for (const char *p = all; *p;) {
+    const char *end = std::strchr(p, ';');
+    const size_t len = end ? (size_t)(end - p) : std::strlen(p);
+    if (len > klen && std::strncmp(p, key, klen) == 0 && p[klen] == '=') {
+      value.assign(p + klen + 1, len - klen - 1);
+      return value.c_str();
+    }
+    if (!end) break;
+    p = end + 1;
+  }
+  return nullptr;
+}
+
 int fail_hip(orbgpu_ctx *ctx, hipError_t e, const char *expr, const char *file, int line) {
   return fail(ctx, ORBGPU_E_HIP,
               std::string("HIP error '") + hipGetErrorString(e) + "' in " + expr + " at " + file + ":" + std::to_string(line));
@@ -544,22 +562,22 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
   ctx->params = *params;
   ctx->device = params->device;
   {
-    const char *z = std::getenv("ORBGPU_NO_ZERO_COPY");
+    const char *z = orbgpu_tune("no_zero_copy");
     ctx->no_zero_copy = z && z[0] == '1';
-    const char *lt = std::getenv("ORBGPU_STAGE_TIMING");  // 1: start with every stage boundary timed
+    const char *lt = orbgpu_tune("stage_timing");  // 1: start with every stage boundary timed
     ctx->stage_timing = lt && lt[0] == '1';
-    const char *ws = std::getenv("ORBGPU_WINDOW_SCAN");  // 1: windowed searches by the plain scan, never the grid
+    const char *ws = orbgpu_tune("window_scan");  // 1: windowed searches by the plain scan, never the grid
     ctx->window_plain_scan = ws && ws[0] == '1';
-    const char *wg = std::getenv("ORBGPU_WINDOW_GRID_MIN");  // tuning / tests: smallest n_from that takes the grid
+    const char *wg = orbgpu_tune("window_grid_min");  // tuning / tests: smallest n_from that takes the grid
     if (wg) ctx->window_grid_min_from = std::max(1, std::atoi(wg));
     ctx->window_grid_forced = wg != nullptr;
-    const char *ls = std::getenv("ORBGPU_LINK_SCAN");  // 1: large-capacity frame links by the plain scan, not the grid
+    const char *ls = orbgpu_tune("link_scan");  // 1: large-capacity frame links by the plain scan, not the grid
     ctx->link_plain_scan = ls && ls[0] == '1';
-    const char *pb = std::getenv("ORBGPU_PATCH_BLUR");  // 0 / 1: full-frame blur / per-keypoint patch blur whatever the size
+    const char *pb = orbgpu_tune("patch_blur");  // 0 / 1: full-frame blur / per-keypoint patch blur whatever the size
     ctx->patch_blur_forced = pb ? (pb[0] == '1' ? 1 : 0) : -1;
-    const char *ng = std::getenv("ORBGPU_NO_GRAPH");  // 1: single-frame host calls enqueue eagerly instead of replaying a hipGraph
+    const char *ng = orbgpu_tune("no_graph");  // 1: single-frame host calls enqueue eagerly instead of replaying a hipGraph
     ctx->graph_single_frame = !(ng && ng[0] == '1');
-    const char *o = std::getenv("ORBGPU_SLICES");  // tuning aid: slices per batch, 0 / unset = automatic
+    const char *o = orbgpu_tune("slices");  // tuning aid: slices per batch, 0 / unset = automatic
     ctx->n_slices = o ? std::atoi(o) : 0;
   }
   auto bail = [&](int rc) {
@@ -607,9 +625,9 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(hipMemcpyAsync(ctx->d_ytab, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice, ctx->stream));
     {
       std::vector<short> rs;
-      const char *rk = std::getenv("ORBGPU_RESIZE");  // ORBGPU_RESIZE=tiles: the LDS-tiled kernel for every level
+      const char *rk = orbgpu_tune("resize");  // ORBGPU_RESIZE=tiles: the LDS-tiled kernel for every level
       const bool tiles = rk && std::string(rk) == "tiles";
-      const char *rt = std::getenv("ORBGPU_RESIZE_STRIPS");  // tuning aid: strips per frame a level should reach
+      const char *rt = orbgpu_tune("resize_strips");  // tuning aid: strips per frame a level should reach
       // a one-frame context (max_batch == 1: the online call shape) is bound by the latency of the chain, not by
       // throughput: short strips give a level's single frame enough waves (orbgpu_extract 179 -> 162 us host to host)
       const int rs_target = rt ? std::atoi(rt) : (params->max_batch == 1 ? 256 : 32);
@@ -628,7 +646,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) ctx->rs_nest_of[l] = -1;
       ctx->n_rs_nest = 0;
       std::vector<std::pair<int, int>> plan;
-      if (const char *np = std::getenv("ORBGPU_RESIZE_NEST")) {
+      if (const char *np = orbgpu_tune("resize_nest")) {
         int a = 0, b = 0, used = 0;
         while (std::sscanf(np, "%d:%d%n", &a, &b, &used) == 2) {
           plan.push_back({a, b});
@@ -636,7 +654,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
           if (*np == ',') np++;
         }
       } else {
-        const char *mp = std::getenv("ORBGPU_RESIZE_NEST_MAXPX");
+        const char *mp = orbgpu_tune("resize_nest_maxpx");
         // one-frame contexts nest every level they can (three launches instead of seven: 162 -> 143 us host to host);
         // batches keep one launch per level (beside level 0's FAST groups the nests measured no gain)
         const long long maxpx = mp ? std::atoll(mp) : (params->max_batch == 1 ? LLONG_MAX : 0);
@@ -676,9 +694,9 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       ctx->n_fast_groups_l0 = 0;
       for (size_t q = 0; q < groups.size(); q += 4)
         if (groups[q] == 0) ctx->n_fast_groups_l0++;
-      const char *nov = std::getenv("ORBGPU_NO_OVERLAP");
+      const char *nov = orbgpu_tune("no_overlap");
       ctx->no_overlap = nov && nov[0] == '1';
-      const char *el0 = std::getenv("ORBGPU_EARLY_L0");
+      const char *el0 = orbgpu_tune("early_l0");
       ctx->early_l0 = g.levels >= 2 && !(el0 && el0[0] == '0');
       HIP_TRY(dmalloc(&ctx->d_fast_groups, groups.size()));
       HIP_TRY(hipMemcpy(ctx->d_fast_groups, groups.data(), groups.size() * sizeof(short), hipMemcpyHostToDevice));
@@ -698,7 +716,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     {
       // levels from this many pixels on get the first rounds of their quadtree presorted by several workgroups
       // (k_qt_presort); ORBGPU_QT_PRESORT_MINPX overrides (0: every level, negative: none)
-      const char *pm = std::getenv("ORBGPU_QT_PRESORT_MINPX");
+      const char *pm = orbgpu_tune("qt_presort_minpx");
       const long long minpx = pm ? std::atoll(pm) : 400000;
       ctx->qt_ps_levels = 0;
       while (minpx >= 0 && ctx->qt_ps_levels < g.levels &&
@@ -708,7 +726,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       // the blur then forks behind the presort launches, beside k_quadtree: forked behind FAST as usual it takes the
       // chip first and the short presort launches wait for it to drain (4K: the scan launch 12 -> 320 us);
       // ORBGPU_PS_BLUR=early restores that order (tuning aid)
-      const char *bl = std::getenv("ORBGPU_PS_BLUR");
+      const char *bl = orbgpu_tune("ps_blur");
       ctx->qt_ps_blur_late = !(bl && bl[0] == 'e');
     }
     // the error flag lives in pinned host memory that the device writes directly (only ever in the error case): no copy

@@ -976,7 +976,7 @@ int launch_quadtree(const orbgpu_ctx *c, FrameSlice fs, const int *budget) {
   // a level of a VGA-class image holds a few thousand candidates: 256 threads keep its short dependent rounds cheap
   // (measured with 512: 0.15 -> 0.34 ms per 256-frame batch); from about a megapixel on a round moves tens of thousands
   // of keys and 1024 threads win (1080p: 0.72 -> 0.57 ms per 64 frames, 4K: 1.27 -> 0.50 ms per 32 frames)
-  const char *force = getenv("ORBGPU_QT_THREADS");  // tuning aid: 256 or 1024
+  const char *force = orbgpu_tune("qt_threads");  // tuning aid: 256 or 1024
   const bool big = force ? atoi(force) > 256 : (long long)g.lv[0].w * g.lv[0].h > 1024 * 768;
   const void *fn = nodes_global ? (big ? reinterpret_cast<const void *>(k_quadtree<1024, true>) : reinterpret_cast<const void *>(k_quadtree<256, true>))
                                 : (big ? reinterpret_cast<const void *>(k_quadtree<1024, false>) : reinterpret_cast<const void *>(k_quadtree<256, false>));
@@ -993,7 +993,7 @@ int launch_quadtree(const orbgpu_ctx *c, FrameSlice fs, const int *budget) {
     for (int l = 0; l < c->qt_ps_levels; l++) a.ps_depth[l] = c->qt_ps_depth[l];
   }
   a.prof = nullptr;
-  const bool profile = getenv("ORBGPU_QT_PROFILE") != nullptr;
+  const bool profile = orbgpu_tune("qt_profile") != nullptr;
   if (profile && hipMalloc(&a.prof, 64 * 8) == hipSuccess) (void)hipMemset(a.prof, 0, 64 * 8);
   const dim3 grid(n_frames, g.levels);
   if (nodes_global) {

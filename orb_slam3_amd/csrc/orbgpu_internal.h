@@ -107,7 +107,7 @@ struct orbgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // where the context enqueues: its own stream, or the caller's (orbgpu_set_stream)
   hipStream_t own_stream = nullptr;
-  static constexpr int MAX_SLICES = 4;
+  static constexpr int MAX_SLICES = 2;  // two slices gained 1.7 % on the headline batch, three and four lost: not kept
   hipStream_t slice_stream[MAX_SLICES]{};  // slices 1.. of a batch (slice 0 runs on `stream`)
   hipStream_t slice_l0[MAX_SLICES]{};      // level 0's FAST launch of a slice runs beside its resize chain
   hipStream_t slice_blur[MAX_SLICES]{};    // the blur of a slice runs beside its (latency-bound) quadtree kernel
@@ -206,6 +206,9 @@ struct orbgpu_vocab {
 };
 
 int fail(orbgpu_ctx *ctx, int code, const std::string &msg);
+// Tuning / test switches live in ONE environment variable, ORBGPU_TUNE="key=value;key=value" (INTEGRATION.md lists the
+// keys); returns the value of `key` or nullptr.  The pointer is valid until the calling thread's next call.
+const char *orbgpu_tune(const char *key);
 int fail_hip(orbgpu_ctx *ctx, hipError_t e, const char *expr, const char *file, int line);
 
 // ---- kernel launchers (each defined next to its kernels) ----

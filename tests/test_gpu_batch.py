@@ -353,9 +353,9 @@ def test_caller_stream_and_capacity_flag(oracle):
     fe.close()
 
 
-@pytest.mark.parametrize("switch", ["ORBGPU_EARLY_L0=0", "ORBGPU_NO_OVERLAP=1", "ORBGPU_RESIZE=tiles", "slices=2",
-                                    "ORBGPU_QT_PRESORT_MINPX=0", "ORBGPU_QT_PRESORT_MINPX=0;slices=2",
-                                    "ORBGPU_QT_PRESORT_MINPX=0;ORBGPU_PS_BLUR=early", "ORBGPU_RESIZE_NEST=4:3"])
+@pytest.mark.parametrize("switch", ["early_l0=0", "no_overlap=1", "resize=tiles", "slices=2", "qt_presort_minpx=0",
+                                    "qt_presort_minpx=0;slices=2", "qt_presort_minpx=0;ps_blur=early",
+                                    "resize_nest=4:3", "patch_blur=1"])
 def test_schedules_give_identical_results(monkeypatch, switch):
     """the stage schedule (level 0's FAST launch beside the resize chain, blur beside quadtree and orientation, frame
     slices), the resize kernels and the quadtree presort are choices of speed only: each alternative writes the same
@@ -370,16 +370,9 @@ def test_schedules_give_identical_results(monkeypatch, switch):
     d_imgs = torch.from_numpy(frames).to(dev)
 
     def run(env):
-        parts = env.split(";") if env else []
-        keys = []
-        for part in parts:
-            if not part.startswith("slices"):
-                k, v = part.split("=")
-                monkeypatch.setenv(k, v)
-                keys.append(k)
+        if env:
+            monkeypatch.setenv("ORBGPU_TUNE", env)     # one variable, "key=value;key=value"
         fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_batch=B, max_features=NF)
-        if "slices=2" in parts:
-            assert lib.orbgpu_set_batch_slices(fe.handle, 2) == 0
         cap = fe.geometry(NF).keypoint_capacity
         d_kp = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
         d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
@@ -392,8 +385,7 @@ def test_schedules_give_identical_results(monkeypatch, switch):
         assert lib.orbgpu_synchronize(fe.handle) == 0
         out = d_kp.cpu().numpy(), d_desc.cpu().numpy(), d_n.cpu().numpy()
         fe.close()
-        for k in keys:
-            monkeypatch.delenv(k)
+        monkeypatch.delenv("ORBGPU_TUNE", raising=False)
         return out
 
     ref = run(None)

@@ -214,9 +214,9 @@ def test_resize_kernels_agree(oracle, monkeypatch):
     okp, odesc = oracle.extract_literal(oracle.params(w, h, 1.2, 8, 20, 7), img, nfeat)
     for mode in ("tiles", None):
         if mode:
-            monkeypatch.setenv("ORBGPU_RESIZE", mode)
+            monkeypatch.setenv("ORBGPU_TUNE", "resize=" + mode)
         else:
-            monkeypatch.delenv("ORBGPU_RESIZE", raising=False)
+            monkeypatch.delenv("ORBGPU_TUNE", raising=False)
         fe = ORBFeatureExtractor(w, h, 1.2, 8, 20, 7, max_features=nfeat)
         ft = Features(w, h)
         assert fe.Extract(img, ft, nfeat) == 0
@@ -246,7 +246,7 @@ def test_extract_quadtree_presorted(oracle, monkeypatch, w, h, nfeat, levels, se
     img = _scene(scene, seed, h, w)
     okp, odesc = oracle.extract_literal(oracle.params(w, h, levels=levels), img, nfeat)
     for minpx in ("0", "-1"):
-        monkeypatch.setenv("ORBGPU_QT_PRESORT_MINPX", minpx)
+        monkeypatch.setenv("ORBGPU_TUNE", "qt_presort_minpx=" + minpx)
         fe = ORBFeatureExtractor(w, h, 1.2, levels, 20, 7, max_features=nfeat)
         ft = Features(w, h)
         assert fe.Extract(img, ft, nfeat) == 0
@@ -265,7 +265,7 @@ def test_resize_nest_agrees(oracle, monkeypatch, w, h, plan):
     img = synth.frame(91, h, w)
     p = oracle.params(w, h, 1.2, levels, 20, 7)
     okp, odesc, ex = oracle.extract(p, img, 800, dump=True)
-    monkeypatch.setenv("ORBGPU_RESIZE_NEST", plan)
+    monkeypatch.setenv("ORBGPU_TUNE", "resize_nest=" + plan)
     fe = ORBFeatureExtractor(w, h, 1.2, levels, 20, 7, max_features=800)
     ft = Features(w, h)
     assert fe.Extract(img, ft, 800) == 0
@@ -280,7 +280,7 @@ def test_resize_nest_agrees(oracle, monkeypatch, w, h, plan):
 def test_single_frame_graph_recapture_and_eager(oracle, monkeypatch):
     """orbgpu_extract replays ONE captured hipGraph per feature_count (results land in mapped host memory): a context asked
     for 500, then 1000, then 500 keypoints again re-captures each time and stays bit-exact, the frame changes between
-    replays of one graph, and ORBGPU_NO_GRAPH=1 (eager launches, copies back) gives the same."""
+    replays of one graph, and ORBGPU_TUNE=no_graph=1 (eager launches, copies back) gives the same."""
     from orb_slam3_amd.features import ORBFeatureExtractor, Features
     w, h = 640, 480
     frames = synth.sequence(61, 3, h, w)
@@ -288,7 +288,7 @@ def test_single_frame_graph_recapture_and_eager(oracle, monkeypatch):
     want = {(f, nf): oracle.extract(p, frames[f], nf) for f in range(3) for nf in (500, 1000)}
     for no_graph in (None, "1"):
         if no_graph:
-            monkeypatch.setenv("ORBGPU_NO_GRAPH", no_graph)
+            monkeypatch.setenv("ORBGPU_TUNE", "no_graph=" + no_graph)
         fe = ORBFeatureExtractor(w, h, 1.2, 8, 20, 7, max_features=1000)
         for f, nf in ((0, 500), (1, 500), (2, 1000), (0, 1000), (1, 500), (2, 500), (0, 1000)):
             ft = Features(w, h)
@@ -307,7 +307,7 @@ def test_single_frame_graph_recapture_and_eager(oracle, monkeypatch):
     (1280, 720, 3000, 8, 74, "rich"),
 ])
 def test_patch_blur_mode(oracle, monkeypatch, w, h, nfeat, levels, seed, scene):
-    """ORBGPU_PATCH_BLUR=1 forces the per-keypoint path (k_patch_describe: orientation + 7 x 7 blur of the keypoint's own
+    """ORBGPU_TUNE=patch_blur=1 forces the per-keypoint path (k_patch_describe: orientation + 7 x 7 blur of the keypoint's own
     43 x 43 patch + rBRIEF in one kernel, by default only where the patches cover well under the pyramid, e.g. 4K / 5000):
     keypoints, angles and descriptors against the oracle -- i.e. against the full-frame cv::GaussianBlur with
     BORDER_REFLECT_101 -- and the blurred levels of the stage dump (produced on demand in this mode) as well."""
@@ -315,7 +315,7 @@ def test_patch_blur_mode(oracle, monkeypatch, w, h, nfeat, levels, seed, scene):
     img = _scene(scene, seed, h, w)
     p = oracle.params(w, h, levels=levels)
     okp, odesc, ex = oracle.extract(p, img, nfeat, dump=True)
-    monkeypatch.setenv("ORBGPU_PATCH_BLUR", "1")
+    monkeypatch.setenv("ORBGPU_TUNE", "patch_blur=1")
     for max_batch in (1, 2):               # the captured single-frame graph and the eager batch path
         fe = ORBFeatureExtractor(w, h, 1.2, levels, 20, 7, max_batch=max_batch, max_features=nfeat)
         ft = Features(w, h)

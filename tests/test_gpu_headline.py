@@ -103,7 +103,7 @@ def test_batch_4k_frames(oracle):
 
 def test_large_capacity_link_grid_equals_plain_scan(oracle):
     """Above the fused link kernel's capacity orbgpu_match_frames_device bins the level-0 rows by the 64 x 48 search grid
-    (k_link_grid); ORBGPU_LINK_SCAN=1 keeps the plain predicated scan.  Same matches, distances and counts, on pairs that
+    (k_link_grid); ORBGPU_TUNE=link_scan=1 keeps the plain predicated scan.  Same matches, distances and counts, on pairs that
     share frames in both roles (a frame linked to two others, and in both directions), with and without the rotation
     filter, for windows of 100 and 30 px; one pair is checked against the oracle as well."""
     import os
@@ -118,11 +118,11 @@ def test_large_capacity_link_grid_equals_plain_scan(oracle):
     res = {}
     for mode in ("grid", "scan"):
         if mode == "scan":
-            os.environ["ORBGPU_LINK_SCAN"] = "1"
+            os.environ["ORBGPU_TUNE"] = "link_scan=1"
         try:
             fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_batch=B, max_features=NF)
         finally:
-            os.environ.pop("ORBGPU_LINK_SCAN", None)
+            os.environ.pop("ORBGPU_TUNE", None)
         cap = fe.geometry(NF).keypoint_capacity
         d_imgs = torch.from_numpy(frames).to(dev)
         d_kp = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)

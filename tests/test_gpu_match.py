@@ -503,8 +503,8 @@ def test_grid_segments_flags_an_understated_maximum(fe):
 @pytest.mark.parametrize("n_to,n_from,grid_min", [(300, 280, "1"), (64, 256, "1"), (2500, 2600, None), (1000, 5000, None)])
 def test_single_window_search_over_the_grid(oracle, n_to, n_from, grid_min):
     """orbgpu_match_window (host pointers, one search: the call SNNMatcher<ProjectionSearchIterator> makes) takes the search
-    grid from 2048 'from' rows on (ORBGPU_WINDOW_GRID_MIN lowers that for the small cases here): same results as the
-    oracle and as a context that never uses the grid (ORBGPU_WINDOW_SCAN=1)."""
+    grid from 2048 'from' rows on (ORBGPU_TUNE=window_grid_min=.. lowers that for the small cases here): same results as
+    the oracle and as a context that never uses the grid (ORBGPU_TUNE=window_scan=1)."""
     import os
     from orb_slam3_amd import _lib
     from orb_slam3_amd.features import ORBFeatureExtractor
@@ -530,7 +530,7 @@ def test_single_window_search_over_the_grid(oracle, n_to, n_from, grid_min):
     omf, omd = oracle.snn_match(to_desc, from_desc, 100, 0.9, to_xy=to_xy, to_window=win, to_min_level=lmin,
                                 to_max_level=lmax, to_active=active, from_xy=from_xy, from_level=from_lv)
     assert (omf >= 0).sum() > k // 3
-    for env in ({"ORBGPU_WINDOW_GRID_MIN": grid_min} if grid_min else {}, {"ORBGPU_WINDOW_SCAN": "1"}):
+    for env in ({"ORBGPU_TUNE": "window_grid_min=" + grid_min} if grid_min else {}, {"ORBGPU_TUNE": "window_scan=1"}):
         os.environ.update(env)
         try:
             ctx = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_features=1000)
