@@ -350,10 +350,10 @@ def main():
     # then ONE all-gather and the all-pairs keyframe matching (rows = own keyframes).  Two legs: frames crossing PCIe
     # from pinned host memory, and the same loop fed from an HBM-resident pool.  Reported beside `value`, never in it.
     sequence = None
-    if not args.no_sequence and headline:
+    if not args.no_sequence and (headline or args.sequence_frames != 20000):
         from orb_slam3_amd.sequence import PooledSource, ResidentSource, SequenceRunner
         n_seq = args.sequence_frames
-        pooled = PooledSource(1240, pool_frames=64, height=H, width=W)
+        pooled = PooledSource(1240, pool_frames=min(64, max(B, 8)), height=H, width=W)
         legs = {}
         kf_result = None
         for leg, src in (("pcie_inclusive", pooled), ("hbm_resident", ResidentSource(pooled, dev))):
@@ -445,17 +445,17 @@ def main():
     # HBM-side bytes per launch from the committed counter passes (tools/profile_round.sh -> profiles/): valid for the
     # default workload only, null otherwise
     traffic, traffic_src, sq = None, None, {}
-    tfile = ROOT / "profiles" / "r2_hbm_traffic.json"
+    tfile = ROOT / "profiles" / "r3_hbm_traffic.json"
     if tfile.exists() and headline:
         tj = json.loads(tfile.read_text())
         traffic = tj["kernels"].get(fast_kernel, {}).get("hbm_bytes")
-        traffic_src = "profiles/r2_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this workload)"
+        traffic_src = "profiles/r3_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this workload)"
         sq = tj.get("sq_counters_per_launch", {})
     # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/):
     # the live figure brackets the launch with two HIP events and so holds the launch's dispatch and the events' own
     # processing (about 10 us) on top of the kernel's duration
     rocprof_ms = None
-    sfile = ROOT / "profiles" / "r2_bench_no_large_kernel_stats.csv"
+    sfile = ROOT / "profiles" / "r3_bench_no_large_kernel_stats.csv"
     if sfile.exists() and headline and early_l0:
         import csv
         want = "k_fast_cells<false, 0>"
@@ -468,14 +468,14 @@ def main():
                 "avg_launch_ms_in_committed_rocprof_stats": rocprof_ms,
                 "avg_launch_ms_source": "live: HIP events on the kernel's stream around the launch (dispatch + the events' own "
                                         "processing included, ~10 us more than the kernel itself); rocprof figure: "
-                                        "profiles/r2_bench_no_large_kernel_stats.csv, valid for the default workload with "
+                                        "profiles/r3_bench_no_large_kernel_stats.csv, valid for the default workload with "
                                         "level 0's launch beside the pyramid",
                 "launch": ("pyramid levels >= 1 of every frame, alone on the device; level 0's groups are a second launch of "
                            "the same kernel (k_fast_cells<false,1>, pipeline.fast_level0) that needs no pyramid and runs "
                            "beside the resize chain") if early_l0 else "all pyramid levels of every frame",
                 "limiter": "not HBM: the kernel (FAST score + per-cell NMS, fallback and compaction, fused) issues about one "
                            "vector instruction per clock per CU, the measured ceiling of its mix "
-                           "(profiles/r2_hbm_traffic.json sq_counters_per_launch, profiles/r2_valu_rate.txt), and its time "
+                           "(profiles/r3_hbm_traffic.json sq_counters_per_launch, profiles/r3_valu_rate.txt), and its time "
                            "follows its occupancy (7-8 workgroups of seven barrier-separated phases per CU) and its "
                            "instruction count about one to one (DESIGN.md, 'Tried and set aside in round 2')"}
     # whole extraction against SURVEY 8d's per-frame figure A = 5P - px0 - px7 + 1978 N

@@ -226,8 +226,8 @@ def test_bench_two_ranks_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["ORB_BENCH_REHEARSAL"] = "1"
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--frames", "8", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-bruteforce", "--no-database"], env=env, capture_output=True, text=True,
-                       timeout=280)
+                        "--no-cpu-baseline", "--no-bruteforce", "--no-database", "--sequence-frames", "203"], env=env,
+                       capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -235,3 +235,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["config"]["world_size_observed"] == 2 and out["value"] > 0
     assert out["keyframe_allpairs"]["keyframes_total"] == 4 and out["keyframe_allpairs"]["matches_rank0"] > 0
     assert "not the headline" in out["config"]["workload"]
+    # the offline sequence, block-sharded over the two ranks (102 + 101 frames, one halo frame, 21 keyframes gathered)
+    seq = out["sequence"]
+    assert seq["frames"] == 203 and seq["keyframes_total"] == 21 and seq["pcie_inclusive"]["frames_per_s"] > 0
+    assert seq["keyframe_allpairs"]["matches_rank0"] > 0 and "all_gather" in seq["keyframe_allpairs"]["exchange"]
+    assert seq["keyframe_allpairs_mfma_i8_exploration"]["identical_to_popcount_results"] is True

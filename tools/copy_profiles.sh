@@ -2,7 +2,7 @@
 # copies the summaries tools/profile_round.sh left under gpurun_out/prof_TAG into profiles/TAG_*.  Usage: tools/copy_profiles.sh TAG
 set -e
 # (gpurun merges new files into gpurun_out/: remove gpurun_out/prof_TAG before a new profile round, or stale traces stay beside the new ones)
-TAG=${1:-r2}
+TAG=${1:-r3}
 O=gpurun_out/prof_$TAG
 cp "$(ls -t $O/trace/*/*kernel_stats.csv | head -1)" profiles/${TAG}_bench_kernel_stats.csv
 cp "$(ls -t $O/trace_no_large/*/*kernel_stats.csv | head -1)" profiles/${TAG}_bench_no_large_kernel_stats.csv
