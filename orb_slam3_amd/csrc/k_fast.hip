@@ -6,7 +6,9 @@
 //   d_k = v - ring_k,  M_dark = max over the 16 arcs of min over 9 contiguous d,
 //   M_bright = max over arcs of min(-d),  score = max(M_dark, M_bright) - 1,  corner at t  <=>  score >= t.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "orbgpu_internal.h"
@@ -72,6 +74,47 @@ __device__ __forceinline__ u16x2 pair_bytes(const unsigned (&w)[3]) {
   return as_u16x2(__builtin_amdgcn_perm(hi, w[lo], sel));
 }
 
+// Quick test of the 4 pixels of a quad on bytes, without widening: pixels quantised to 6 bits (p >> 2) leave two
+// spare bits per byte, so with a = (t + 1) >> 2 the byte-wise sums v6 + (128 - a) - r6 and r6 + (128 - a) - v6 neither
+// borrow nor carry across bytes and have bit 7 set exactly when v6 - r6 >= a / r6 - v6 >= a.  A corner at threshold t has
+// 9 contiguous ring pixels all <= v - t - 1 (or all >= v + t + 1), hence one of every opposite pair, and
+// r <= v - t - 1 implies r >> 2 <= (v >> 2) - a: the quantised test passes every pixel the exact one passes (and a few
+// more: 6.7 % instead of 6.2 % of the pixels at t = 20).  The exact score decides afterwards.  Four opposite pairs (the
+// even ring positions); only full-rate operations (shift, and, or, add, sub) but for six v_alignbyte_b32.
+// tw -> dword left of the quad in tile row y - 3.  Returns bit 7 of byte p set <=> pixel p may be a corner at `ka`'s
+// threshold (BOTH: at ka's and not at kb's).
+__device__ __forceinline__ unsigned quant6(unsigned x) {
+  unsigned m = 0x3f3f3f3fu;
+  asm volatile("" : "+s"(m));
+  return (x >> 2) & m;
+}
+
+// one v_bitop3_b32
+__device__ __forceinline__ unsigned or_and(unsigned x, unsigned y, unsigned z) { return (x | y) & z; }
+
+// RAW: the tile holds the pixels themselves (quantised here); else the tile quantised at staging time
+template <bool RAW, bool BOTH>
+__device__ __forceinline__ unsigned quick_quad(const unsigned *tw, unsigned ka, unsigned kb) {
+  constexpr int TP = 36;  // FC_TP
+  auto qz = [](unsigned x) { return RAW ? quant6(x) : x; };
+  const unsigned r0 = qz(tw[6 * TP + 1]), r8 = qz(tw[1]);                         // (0, 3), (0, -3)
+  const unsigned pa = tw[5 * TP], pb = tw[5 * TP + 1], pc = tw[5 * TP + 2];       // row y + 2: (2, 2), (-2, 2)
+  const unsigned r2 = qz(__builtin_amdgcn_alignbyte(pc, pb, 2)), r14 = qz(__builtin_amdgcn_alignbyte(pb, pa, 2));
+  const unsigned ma = tw[TP], mb = tw[TP + 1], mc = tw[TP + 2];                   // row y - 2: (2, -2), (-2, -2)
+  const unsigned r6 = qz(__builtin_amdgcn_alignbyte(mc, mb, 2)), r10 = qz(__builtin_amdgcn_alignbyte(mb, ma, 2));
+  const unsigned ca = tw[3 * TP], cb = tw[3 * TP + 1], cc = tw[3 * TP + 2];       // row y: (3, 0), (-3, 0), centre
+  const unsigned r4 = qz(__builtin_amdgcn_alignbyte(cc, cb, 3)), r12 = qz(__builtin_amdgcn_alignbyte(cb, ca, 1));
+  const unsigned v = qz(cb);
+  auto test = [&](unsigned k) {
+    const unsigned va = v + k, vb = k - v;
+    const unsigned dark = or_and(va - r6, va - r14, or_and(va - r4, va - r12, or_and(va - r2, va - r10, (va - r0) | (va - r8))));
+    const unsigned bright = or_and(r6 + vb, r14 + vb, or_and(r4 + vb, r12 + vb, or_and(r2 + vb, r10 + vb, (r0 + vb) | (r8 + vb))));
+    return dark | bright;
+  };
+  if (BOTH) return test(ka) & ~test(kb);
+  return test(ka);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused FAST score + per-cell NMS + threshold fallback + compaction on CELL-ALIGNED tiles.
 //
@@ -90,7 +133,22 @@ __device__ __forceinline__ u16x2 pair_bytes(const unsigned (&w)[3]) {
 //            fixed slot of the candidate pool, CellEntry written.
 // No score map, no bit plane and no second kernel: the only global traffic is the tile read and the candidates.
 // DUMP = true additionally scatters the non-zero scores into a global score map (orbgpu_debug_dump's stage test).
-struct FastGroup { short level, row, j0, ncell; };  // cells j0 .. j0 + ncell - 1 of cell row `row`
+struct FastGroup { short level, row, j0, ncell; };
+
+// -DORBGPU_FAST_PROFILE (debugging aid, never in the shipped library): wave 0 of every workgroup adds the 100 MHz
+// clock ticks it spent in each phase to fc_prof[phase], the launch prints the means
+#ifdef ORBGPU_FAST_PROFILE
+constexpr int FC_PROF_WG = 65536;
+__device__ unsigned fc_prof[FC_PROF_WG * 16];  // [workgroup][phase]: ticks; [15]: 1 + (took the minThFAST round)
+#define FC_STAMP(i)                                                                   \
+  do {                                                                                \
+    const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();                \
+    if (tid == 0 && prof_wg < FC_PROF_WG) fc_prof[prof_wg * 16 + (i)] = (unsigned)(t_now - t_prev); \
+    t_prev = t_now;                                                                   \
+  } while (0)
+#else
+#define FC_STAMP(i) do { } while (0)
+#endif  // cells j0 .. j0 + ncell - 1 of cell row `row`
 
 constexpr int FC_TP = 36;               // dwords per staged / score row (<= 33 quads + 2 apron dwords)
 constexpr int FC_TPB = FC_TP * 4;
@@ -101,7 +159,7 @@ constexpr int FC_MAXROWS = 64;          // rows of a cell (hcell <= 64 is checke
 __host__ __device__ constexpr size_t fast_cells_lds_bytes(int rows) {
   return (size_t)(rows + 6) * FC_TPB       // pixel tile
          + (size_t)(rows + 2) * FC_TPB     // score tile
-         + (size_t)rows * FC_QPITCH * 2    // survivor queue (u16)
+         + (size_t)std::max(rows * FC_QPITCH * 2, (rows + 6) * FC_TPB)  // survivor queue (u16); before it the quantised tile
          + (size_t)rows * FC_MAXK * 8      // row mask per (row, cell): kept (u64); 8 workgroups per CU need <= 20 KB
          + FC_TP * 4                       // column validity mask per quad
          + 16;
@@ -140,6 +198,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   unsigned *tile = fc_lds;
   unsigned *stile = tile + (lds_rows + 6) * FC_TP;
   unsigned short *queue = reinterpret_cast<unsigned short *>(stile + (lds_rows + 2) * FC_TP);
+  unsigned *qtile = reinterpret_cast<unsigned *>(queue);  // the tile quantised for the quick test, until the first push
   // [row][cell] u64: pixels kept by NMS -- at iniThFAST first; a cell that kept nothing then (its masks are still zero)
   // is the only kind the minThFAST pass writes to, so one mask serves both passes
   unsigned *rmask = reinterpret_cast<unsigned *>(queue + lds_rows * FC_QPITCH);
@@ -147,11 +206,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   int *q_count = reinterpret_cast<int *>(colmask + FC_TP);
   int item, frame;
   if (!xcd_item_frame(groups_per_frame, n_frames, item, frame)) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const FastGroup G = groups[item];
   const int l = G.level;
   const LevelGeom L = g.lv[l];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef ORBGPU_FAST_PROFILE
+  const unsigned prof_wg = blockIdx.x;
+  unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
+  if (tid == 0 && prof_wg < FC_PROF_WG) fc_prof[prof_wg * 16 + 15] = 1;
+#endif
   // detection rectangle of the group: rows of cell row G.row, columns of cells j0 .. j0 + ncell - 1
   const int Y0 = ORB_EDGE + G.row * L.hcell, Y1 = min(ORB_EDGE - 1 + (G.row + 1) * L.hcell, L.h - ORB_EDGE - 1);
   const int X0 = ORB_EDGE + G.j0 * L.wcell, X1 = min(ORB_EDGE - 1 + (G.j0 + G.ncell) * L.wcell, L.w - ORB_EDGE - 1);
@@ -165,24 +229,29 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   const int xs0 = X0 & ~3;                         // first quad column; tile byte column c <-> level x = xs0 - 4 + c
   const int ncg = ((X1 - xs0) >> 2) + 1;           // quads per row, <= 33
   const int ndw = ncg + 2;                         // staged dwords per row
-  const int nq4 = ncg * nrow;
   const uint8_t *src = level_src(pyr, g, lvl0, frame, l, L.off) + (size_t)(Y0 - 3) * L.pitch + (xs0 - 4);
 
   // ---- stage (nrow + 6) x ndw dwords: wave = row (w, w + 4, ...), lane = dword; every address is inside the image
   //      (Y0 >= 19, Y1 <= h - 20, X1 <= w - 20).  All loads of a wave are issued before its first LDS write ----
+  FC_STAMP(0);  // set-up
   {
     constexpr int NR = (FC_MAXROWS + 6 + 3) / 4;
     const int nst = nrow + 6;
     unsigned v[NR];
     // lanes beyond the row's dwords repeat its last dword (same address, same LDS slot): no per-lane predicate
     const int ln = min(lane, ndw - 1);
-    const uint8_t *lsrc = src + 4 * ln;
+    const unsigned loff = 4u * (unsigned)ln;
+    const uint8_t *rowp = src + (size_t)wave * L.pitch;
+    const size_t rstep = 4 * (size_t)L.pitch;
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-      const int r = wave + 4 * k;  // wave-uniform
+      const int r = wave + 4 * k;  // wave-uniform: the row's address is scalar, the lane adds its 32-bit offset
       v[k] = 0;
-      if (r < nst) v[k] = *reinterpret_cast<const unsigned *>(lsrc + (size_t)r * L.pitch);
+      // (written out: the compiler folds the lane offset into a 64-bit per-lane address, 3 vector instructions a row)
+      if (r < nst) asm volatile("global_load_dword %0, %1, %2" : "=v"(v[k]) : "v"(loff), "s"(rowp));
+      rowp += rstep;
     }
+    FC_STAMP(1);  // loads issued
     // meanwhile: clear the score tile and the row masks (16 bytes per lane and store), per-quad column masks
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < (nrow + 2) * (FC_TP / 4); i += 256) reinterpret_cast<uint4 *>(stile)[i] = z4;
@@ -197,121 +266,119 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
       }
       colmask[tid] = m;
     }
+    FC_STAMP(2);  // clears
+    static_assert(NR == 18, "the wait below names every staged register");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]),
+                   "+v"(v[17]));
+    // (the row count once more, opaque: otherwise the 18 row predicates of the load loop stay live in 36 scalar registers)
+    int nst2 = nst;
+    asm volatile("" : "+s"(nst2));
 #pragma unroll
     for (int k = 0; k < NR; k++) {
       const int r = wave + 4 * k;
-      if (r < nst) tile[r * FC_TP + ln] = v[k];
+      if (r < nst2) {
+        tile[r * FC_TP + ln] = v[k];
+        qtile[r * FC_TP + ln] = quant6(v[k]);
+      }
     }
   }
+  FC_STAMP(3);  // set-up + staging issued
   __syncthreads();
+  FC_STAMP(4);  // staging landed
 
   const int t_lo = g.fast_min, t_hi = g.fast_init;
-  const float inv_ncg = 1.0f / (float)ncg;
-  // candidate at threshold t <=> M = max(v - max_k min(pair_k), min_k max(pair_k) - v) > t: with saturating u16
-  // arithmetic M + (255 - t) has bit 8 set exactly then.  Two thresholds, one M.
-  const unsigned short bias_lo = (unsigned short)(255 - t_lo), bias_hi = (unsigned short)(255 - t_hi);
-  const u16x2 bias_lo2 = {bias_lo, bias_lo}, bias_hi2 = {bias_hi, bias_hi};
-  // the lane's quad of pass k is q = tid + 256 k = (row ry, quad column cq), advanced by (d_r, d_c) per pass
-  int ry = div_small(tid, ncg, inv_ncg), cq = tid - ry * ncg;
-  const int d_r = __builtin_amdgcn_readfirstlane(div_small(256, ncg, inv_ncg)), d_c = 256 - d_r * ncg;
   const int qcap = lds_rows * FC_QPITCH;
-  // ---- phase 1 + push, 8 passes (2048 quads) at a time ------------------------------------------------------
-  // Survivors of the quick test at iniThFAST go to the front of the queue.  Those that only pass at minThFAST stay in
-  // the lane's registers (one bit per pixel, keep_lo): a pixel scoring below iniThFAST can neither be kept nor suppress
-  // anything in a cell that keeps a corner at iniThFAST (NMS is a strict > against a value >= iniThFAST), so they are
-  // only pushed (to the back of the queue) and scored when a cell of the group falls back to minThFAST.
-  unsigned keep_lo[2] = {0, 0};  // nq4 <= 33 x 64 quads: two blocks of 2048
-  // one LDS atomic per wave for a block's survivors; the order inside the queue is free.  Entries are (quad << 2 | pixel)
-  auto push_block = [&](unsigned m, int qbase, bool back) {
+  // quantised thresholds of the quick test (quick_quad) and their per-byte constants 128 - a
+  const int a_lo = (t_lo + 1) >> 2, a_hi = (t_hi + 1) >> 2;
+  const unsigned ka_lo = 0x80808080u - 0x01010101u * (unsigned)a_lo, ka_hi = 0x80808080u - 0x01010101u * (unsigned)a_hi;
+  // ---- quick test over the quad columns qa .. qa + nw - 1 of every row.  The 256 threads cover R = 256 / nw whole rows
+  //      per pass: a lane keeps its quad column and walks down the rows r0, r0 + R, ... (no index arithmetic inside the
+  //      loop, the column mask is loaded once); the lanes beyond R * nw idle.  Survivors of up to 8 passes collect in one
+  //      register, bit 8 * p + pass for pixel p of the lane's quad; 16 passes cover 64 rows at R >= 7 (nw <= 33).
+  //      LO = false: the test at iniThFAST on the tile quantised at staging time.  LO = true (only when a cell of the
+  //      group falls back to minThFAST, and then only over the columns of such cells): pixels that pass at minThFAST and
+  //      not at iniThFAST, from the raw tile (the quantised one is the queue by then).  A pixel scoring below iniThFAST can
+  //      neither be kept nor suppress anything in a cell that keeps a corner at iniThFAST (NMS is a strict > against a
+  //      value >= iniThFAST), so the first round needs no more.
+  struct QuickLane { unsigned acc[2]; unsigned e0; int R; };
+  auto quick_round = [&](int qa, int nw, auto lo_tag) -> QuickLane {
+    constexpr bool LO = decltype(lo_tag)::value;
+    const float inv_nw = 1.0f / (float)nw;
+    const int R = __builtin_amdgcn_readfirstlane(div_small(256, nw, inv_nw));
+    const int r0 = div_small(tid, nw, inv_nw), cq = qa + tid - r0 * nw;
+    const bool on = r0 < R;
+    const unsigned cm = colmask[cq];
+    const unsigned *tw = (LO ? tile : qtile) + r0 * FC_TP + cq;
+    const int step = R * FC_TP;
+    QuickLane ql;
+    ql.acc[0] = ql.acc[1] = 0;
+    ql.e0 = ((unsigned)r0 << 8) | (unsigned)(4 * cq);
+    ql.R = R;
+    int row = r0, top = 0;  // top: first row of the pass, wave-uniform
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      unsigned acc = 0;
+#pragma unroll 1
+      for (int k = 0; k < 8 && top < nrow; k++) {
+        if (on && row < nrow) {
+          const unsigned hb = LO ? quick_quad<true, true>(tw, ka_lo, ka_hi) : quick_quad<false, false>(tw, ka_hi, 0u);
+          acc |= ((hb >> 7) & cm) << k;
+        }
+        row += R;
+        top += R;
+        tw += step;
+      }
+      ql.acc[kb] = acc;
+    }
+    return ql;
+  };
+  // one LDS atomic per wave for the survivors of 8 passes (a wave-wide scan gives every lane its place; an atomic per
+  // lane is 14 vector instructions less and keeps the LDS busy for 64 serialised updates: slower); the order inside
+  // the queue is free.  Entries are (row << 8 | tile column - 4).  The atomic is written out because the compiler wraps
+  // an atomicAdd under `lane == 0` into a second reduction over the (one) active lane.
+  const unsigned qc_addr = (unsigned)reinterpret_cast<size_t>(q_count);
+  auto push_block = [&](unsigned m, unsigned e0, int R, bool back) {
     const int cnt = __popc(m);
     const int incl = wave_incl_scan(cnt);
     const int tot = __builtin_amdgcn_readlane(incl, 63);
     if (tot == 0) return;
-    int basep = 0;
-    if (lane == 0) basep = atomicAdd(q_count, back ? tot << 16 : tot);
-    basep = __builtin_amdgcn_readfirstlane(basep);
-    int pos = back ? qcap - 1 - ((basep >> 16) + incl - cnt) : (basep & 0xffff) + incl - cnt;
+    unsigned old = 0;
+    if (lane == 0)
+      asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(qc_addr), "v"(back ? tot << 16 : tot) : "memory");
+    old = __builtin_amdgcn_readfirstlane(old);
+    int pos = back ? qcap - 1 - ((int)(old >> 16) + incl - cnt) : (int)(old & 0xffff) + incl - cnt;
     const int dir = back ? -1 : 1;
-    const unsigned qt = (unsigned)(qbase + tid) << 2;
+    const unsigned rstep = (unsigned)R << 8;
     while (m) {
       const int bit = __ffs(m) - 1;
       m &= m - 1;
-      queue[pos] = (unsigned short)(qt + ((unsigned)(bit & 7) << 10) + ((unsigned)bit >> 3));
+      queue[pos] = (unsigned short)(e0 + (unsigned)(bit & 7) * rstep + ((unsigned)bit >> 3));
       pos += dir;
     }
   };
-  for (int qbase = 0; qbase < nq4; qbase += 2048) {
-    unsigned acc_lo = 0, acc_hi = 0;  // bit 8 * p + pass: pixel p of this lane's quad in pass `pass` may be a corner
-    const int npass = min(8, (nq4 - qbase + 255) >> 8);
-#pragma unroll 1
-    for (int pass = 0; pass < npass; pass++) {
-      if (qbase + 256 * pass + tid < nq4) {
-        const unsigned *tw = tile + ry * FC_TP + cq;
-        // 12-byte windows (columns x-4 .. x+7) of the 7 rows y-3 .. y+3; x = xs0 + 4 cq
-        unsigned w[7][3];
-#pragma unroll
-        for (int j = 0; j < 7; j++)
-#pragma unroll
-          for (int c = 0; c < 3; c++) w[j][c] = tw[j * FC_TP + c];
-        unsigned lo_bytes[2], hi_bytes[2];
-#pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
-          u16x2 r[16];
-          // ring (dx,dy): (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3);
-          // only the even positions are used by the quick test
-          if (pr == 0) {
-            r[0] = pair_bytes<4>(w[6]);  r[2] = pair_bytes<6>(w[5]);  r[4] = pair_bytes<7>(w[3]);  r[6] = pair_bytes<6>(w[1]);
-            r[8] = pair_bytes<4>(w[0]);  r[10] = pair_bytes<2>(w[1]); r[12] = pair_bytes<1>(w[3]); r[14] = pair_bytes<2>(w[5]);
-          } else {
-            r[0] = pair_bytes<6>(w[6]);  r[2] = pair_bytes<8>(w[5]);  r[4] = pair_bytes<9>(w[3]);  r[6] = pair_bytes<8>(w[1]);
-            r[8] = pair_bytes<6>(w[0]);  r[10] = pair_bytes<4>(w[1]); r[12] = pair_bytes<3>(w[3]); r[14] = pair_bytes<4>(w[5]);
-          }
-          const u16x2 v = pr == 0 ? pair_bytes<4>(w[3]) : pair_bytes<6>(w[3]);
-          u16x2 mx_of_min = __builtin_elementwise_min(r[0], r[8]);
-          u16x2 mn_of_max = __builtin_elementwise_max(r[0], r[8]);
-#pragma unroll
-          for (int k = 2; k < 8; k += 2) {
-            mx_of_min = __builtin_elementwise_max(mx_of_min, __builtin_elementwise_min(r[k], r[k + 8]));
-            mn_of_max = __builtin_elementwise_min(mn_of_max, __builtin_elementwise_max(r[k], r[k + 8]));
-          }
-          const u16x2 dk = __builtin_elementwise_sub_sat(v, mx_of_min);   // how far below the centre a dark arc can sit
-          const u16x2 br = __builtin_elementwise_sub_sat(mn_of_max, v);   // how far above a bright one
-          const u16x2 m = __builtin_elementwise_max(dk, br);
-          lo_bytes[pr] = as_u32(m + bias_lo2);
-          hi_bytes[pr] = as_u32(m + bias_hi2);
-        }
-        // bytes 1 and 3 of both results: 0 or 1 per pixel, pixel p in byte p
-        const unsigned cm = colmask[cq];
-        acc_lo |= (__builtin_amdgcn_perm(lo_bytes[1], lo_bytes[0], 0x07050301u) & cm) << pass;
-        acc_hi |= (__builtin_amdgcn_perm(hi_bytes[1], hi_bytes[0], 0x07050301u) & cm) << pass;
-      }
-      cq += d_c;
-      ry += d_r;
-      if (cq >= ncg) {
-        cq -= ncg;
-        ry++;
-      }
-    }
-    if (qbase == 0) keep_lo[0] = acc_lo & ~acc_hi;  // only at minThFAST
-    else keep_lo[1] = acc_lo & ~acc_hi;
-    push_block(acc_hi, qbase, false);
+  auto push_round = [&](const QuickLane &ql, bool back) {
+    push_block(ql.acc[0], ql.e0, ql.R, back);
+    if (8 * ql.R < nrow) push_block(ql.acc[1], ql.e0 + ((unsigned)(8 * ql.R) << 8), ql.R, back);
+  };
+  {
+    const QuickLane ql = quick_round(0, ncg, std::false_type{});
+    FC_STAMP(5);  // quick-test passes
+    __syncthreads();  // the queue takes the place of the quantised tile
+    push_round(ql, false);
   }
+  FC_STAMP(6);  // push
   __syncthreads();
+  FC_STAMP(7);
   const int n_hi = *q_count & 0xffff;
   const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
   uint8_t *sb = reinterpret_cast<uint8_t *>(stile);
   const int bnd0 = X0 - xs0;  // tile column - 4 of the first pixel of cell j0
-  // full 9-arc score of queue entry q -> score tile; the entry becomes (row << 8 | column).  need_mask: cells whose
-  // entries are scored (bit j), all of them for the front of the queue
-  auto score_entry = [&](int q, unsigned need_mask) {
+  // full 9-arc score of queue entry q -> score tile
+  auto score_entry = [&](int q) {
     const int e = queue[q];
-    const int ey = div_small(e >> 2, ncg, inv_ncg), cx = 4 * ((e >> 2) - ey * ncg) + (e & 3);
-    queue[q] = (unsigned short)((ey << 8) | cx);
-    if (need_mask != 0xfu) {
-      const int rel = cx - bnd0;
-      const int j = (rel >= L.wcell) + (rel >= 2 * L.wcell) + (rel >= 3 * L.wcell);
-      if (!((need_mask >> j) & 1u)) return;
-    }
+    const int ey = e >> 8, cx = e & 255;
     const uint8_t *c = tb + (ey + 3) * FC_TPB + cx + 4;
     constexpr int RP = FC_TPB;
     int r[16];
@@ -372,10 +439,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   };
 
   // ---- iniThFAST: score the front of the queue, NMS, emit ---------------------------------------------------------
-  for (int q = tid; q < n_hi; q += 256) score_entry(q, 0xfu);
+  for (int q = tid; q < n_hi; q += 256) score_entry(q);
+  FC_STAMP(8);  // full score
   __syncthreads();
+  FC_STAMP(9);
   for (int q = tid; q < n_hi; q += 256) nms_entry(q, t_hi, 0xfu);
+  FC_STAMP(10);  // NMS
   __syncthreads();
+  FC_STAMP(11);
   if (wave < G.ncell) {
     // a cell without columns (beyond the last detection column) holds nothing at either threshold
     const bool has_cols = X0 + wave * L.wcell <= X1;
@@ -388,16 +459,32 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
       }
     }
   }
+  FC_STAMP(12);  // emit
   __syncthreads();
+  FC_STAMP(13);
   // ---- minThFAST for the cells that kept nothing (orb_feature_extractor.cpp:263-266: decided per cell AFTER NMS) ----
   const unsigned fallback = (unsigned)q_count[1];
   const unsigned score_mask = DUMP ? 0xfu : fallback;
   if (score_mask == 0) return;
-  push_block(keep_lo[0], 0, true);
-  if (nq4 > 2048) push_block(keep_lo[1], 2048, true);
+  // second quick-test round over the quad columns of the cells in score_mask: per-quad masks narrowed to those cells
+  const int j_a = __ffs(score_mask) - 1, j_b = min(31 - __clz(score_mask), (int)G.ncell - 1);
+  const int qa_lo = (X0 + j_a * L.wcell - xs0) >> 2;
+  const int nw_lo = ((min(X0 + (j_b + 1) * L.wcell - 1, X1) - xs0) >> 2) - qa_lo + 1;
+  if (tid < FC_TP) {
+    unsigned m = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int rel = xs0 + 4 * tid + p - X0;
+      const int j = (rel >= L.wcell) + (rel >= 2 * L.wcell) + (rel >= 3 * L.wcell);
+      if (rel >= 0 && rel <= X1 - X0 && ((score_mask >> j) & 1u)) m |= 1u << (8 * p);
+    }
+    colmask[tid] = m;
+  }
+  __syncthreads();
+  push_round(quick_round(qa_lo, nw_lo, std::true_type{}), true);
   __syncthreads();
   const int n_lo = *q_count >> 16;
-  for (int q = qcap - 1 - tid; q >= qcap - n_lo; q -= 256) score_entry(q, score_mask);
+  for (int q = qcap - 1 - tid; q >= qcap - n_lo; q -= 256) score_entry(q);
   if (fallback == 0) return;
   __syncthreads();
   for (int q = tid; q < n_hi; q += 256) nms_entry(q, 1, fallback);
@@ -406,6 +493,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   if (wave < G.ncell && ((fallback >> wave) & 1u)) {
     if (emit_cell(wave) == 0 && lane == 0) ce[wave] = CellEntry{(G.row * L.ncols + G.j0 + wave) * cell_slot, 0};
   }
+  FC_STAMP(14);  // the whole minThFAST round
+#ifdef ORBGPU_FAST_PROFILE
+  if (tid == 0 && prof_wg < FC_PROF_WG) fc_prof[prof_wg * 16 + 15] = 2;
+#endif
 }
 
 }  // namespace
@@ -437,13 +528,13 @@ void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, 
   const int first = part == 0 ? c->n_fast_groups_l0 : 0;
   const int count = part == 1 ? c->n_fast_groups_l0 : c->n_fast_groups - first;
   if (count <= 0) return;
-  dim3 grid(count * xcd_frames(fs.n));
   const FastGroup *groups = reinterpret_cast<const FastGroup *>(c->d_fast_groups) + first;
   // dynamic LDS by the tallest cell of the launch's own levels: 32 rows (level 0 of a VGA frame) fit 8 workgroups per CU,
   // 33 rows and more only 7 -- and the kernel's time follows its occupancy
   int rows = 0;
   for (int l = (part == 0 ? 1 : 0); l < (part == 1 ? 1 : g.levels); l++) rows = std::max(rows, g.lv[l].hcell);
   const size_t lds = fast_cells_lds_bytes(rows);
+  dim3 grid(count * xcd_frames(fs.n));
   const uint8_t *pyr = c->d_pyr + (size_t)fs.f0 * g.frame_bytes;
   CellEntry *cells = c->d_cells + (size_t)fs.f0 * g.cells_per_frame;
   unsigned *cands = c->d_cands + (size_t)fs.f0 * g.cands_per_frame;
@@ -456,6 +547,32 @@ void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, 
   else
     hipLaunchKernelGGL((k_fast_cells<false, 0>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
                        fs.n, slice_lvl0(c, fs), rows, (uint8_t *)nullptr);
+#ifdef ORBGPU_FAST_PROFILE
+  if (part != 1) {
+    static std::vector<unsigned> h(FC_PROF_WG * 16);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fc_prof), h.size() * 4);
+    static const char *nm[15] = {"setup", "load-issue", "clears", "tile-write", "bar", "quick", "push", "bar", "score", "bar", "nms", "bar", "emit", "bar", "fallback"};
+    double sum[15] = {0}, n = 0, nfb = 0;
+    for (unsigned w = 0; w < std::min<unsigned>(grid.x, FC_PROF_WG); w++) {
+      if (!h[w * 16 + 15]) continue;
+      n++;
+      const bool fb = h[w * 16 + 15] == 2;
+      nfb += fb;
+      for (int i = 0; i < (fb ? 15 : 14); i++) sum[i] += h[w * 16 + i];
+    }
+    fprintf(stderr, "FAST profile, %.0f workgroups (%.0f with fallback), mean ticks (10 ns) per workgroup:", n, nfb);
+    double tot = 0;
+    for (int i = 0; i < 15; i++) {
+      fprintf(stderr, " %s %.1f", nm[i], sum[i] / n);
+      tot += sum[i] / n;
+    }
+    fprintf(stderr, " | total %.1f\n", tot);
+    (void)hipMemset(nullptr, 0, 0);
+    std::fill(h.begin(), h.end(), 0u);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(fc_prof), h.data(), h.size() * 4);
+  }
+#endif
 }
 
 

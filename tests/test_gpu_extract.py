@@ -205,6 +205,37 @@ def test_extract_random_configurations(oracle, seed):
     fe.close()
 
 
+@pytest.mark.parametrize("fi,fm", [(1, 1), (2, 1), (3, 2), (4, 3), (20, 20), (23, 19), (100, 60), (254, 200), (255, 255)])
+@pytest.mark.parametrize("kind", ["rich", "noise", "steps"])
+def test_fast_threshold_extremes(oracle, fi, fm, kind):
+    """the quick test of k_fast_cells works on pixels quantised to 6 bits with thresholds (t + 1) >> 2: thresholds at
+    both ends of the range and around multiples of 4, on a scene, on noise and on saturated steps (0 / 255 edges, where
+    the byte-wise sums sit at the ends of their ranges)"""
+    from orb_slam3_amd.features import ORBFeatureExtractor, Features
+    w, h, nfeat = 333, 261, 600
+    if kind == "rich":
+        img = synth.frame(4242, h, w)
+    elif kind == "noise":
+        img = np.random.default_rng(fi * 256 + fm).integers(0, 256, (h, w), dtype=np.uint8)
+    else:
+        rng = np.random.default_rng(99)
+        img = np.zeros((h, w), np.uint8)
+        for _ in range(400):
+            y, x = int(rng.integers(0, h - 6)), int(rng.integers(0, w - 6))
+            img[y:y + int(rng.integers(1, 12)), x:x + int(rng.integers(1, 12))] = int(rng.choice([0, 1, 3, 4, 127, 128, 251, 252, 254, 255]))
+    p = oracle.params(w, h, 1.2, 4, fi, fm)
+    okp, odesc = oracle.extract(p, img, nfeat)
+    fe = ORBFeatureExtractor(w, h, 1.2, 4, fi, fm, max_features=nfeat)
+    ft = Features(w, h)
+    assert fe.Extract(img, ft, nfeat) == 0
+    assert ft.Size() == len(okp)
+    for fld in ("x", "y", "level", "size"):
+        assert np.array_equal(ft.keypoints[fld], okp[fld]), fld
+    assert np.array_equal(ft.keypoints["angle"], okp["angle"].astype(np.float32))
+    assert np.array_equal(ft.descriptors, odesc)
+    fe.close()
+
+
 def test_resize_kernels_agree(oracle, monkeypatch):
     """the LDS-tiled resize kernel (the fallback for steep scale factors) forced for an ordinary pyramid: the same
     keypoints and descriptors as the strip kernel and the oracle"""
