@@ -228,29 +228,32 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   }
   const int xs0 = X0 & ~3;                         // first quad column; tile byte column c <-> level x = xs0 - 4 + c
   const int ncg = ((X1 - xs0) >> 2) + 1;           // quads per row, <= 33
-  const int ndw = ncg + 2;                         // staged dwords per row
   const uint8_t *src = level_src(pyr, g, lvl0, frame, l, L.off) + (size_t)(Y0 - 3) * L.pitch + (xs0 - 4);
 
-  // ---- stage (nrow + 6) x ndw dwords: wave = row (w, w + 4, ...), lane = dword; every address is inside the image
-  //      (Y0 >= 19, Y1 <= h - 20, X1 <= w - 20).  All loads of a wave are issued before its first LDS write ----
+  // ---- stage (nrow + 6) rows of 36 dwords (9 x 16 bytes): a lane loads 16 bytes, 7 rows per wave and load, so the
+  //      whole tile takes two loads a wave (three for the tallest cells) and lands in LDS in lane order.  Rows are
+  //      staged to their full 144 bytes whatever the group's width: the bytes beyond the group's columns belong to the
+  //      same or the following image row (Y1 + 3 <= h - 17, so rows follow), are never used and cost no extra
+  //      instruction.  Buffer loads: the tile's first byte is the (scalar) base, a lane adds a 32-bit offset, and what
+  //      lies beyond the tile's last row is cut off by the descriptor's range (returns 0, touches no memory).  All
+  //      loads of a wave are issued before its first LDS write ----
   FC_STAMP(0);  // set-up
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   {
-    constexpr int NR = (FC_MAXROWS + 6 + 3) / 4;
+    constexpr int NR = (FC_MAXROWS + 6 + 27) / 28;
     const int nst = nrow + 6;
-    unsigned v[NR];
-    // lanes beyond the row's dwords repeat its last dword (same address, same LDS slot): no per-lane predicate
-    const int ln = min(lane, ndw - 1);
-    const unsigned loff = 4u * (unsigned)ln;
-    const uint8_t *rowp = src + (size_t)wave * L.pitch;
-    const size_t rstep = 4 * (size_t)L.pitch;
+    // lane / 9, lane % 9; lane 63 is (row 7, column 0): the first 16 bytes of the next wave's first row once more
+    const int rs = (lane * 57) >> 9, c4 = lane - 9 * rs;
+    const int row0 = 7 * wave + rs;
+    const unsigned pitch = (unsigned)L.pitch;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, (nst - 1) * (int)pitch + FC_TPB, 0x00020000);
+    const unsigned voff = (unsigned)row0 * pitch + 16u * (unsigned)c4;
+    u32x4 v[NR];
 #pragma unroll
-    for (int k = 0; k < NR; k++) {
-      const int r = wave + 4 * k;  // wave-uniform: the row's address is scalar, the lane adds its 32-bit offset
-      v[k] = 0;
-      // (written out: the compiler folds the lane offset into a 64-bit per-lane address, 3 vector instructions a row)
-      if (r < nst) asm volatile("global_load_dword %0, %1, %2" : "=v"(v[k]) : "v"(loff), "s"(rowp));
-      rowp += rstep;
-    }
+    // (unconditional: a load wholly beyond the range moves nothing, and a branch around it would make the compiler wait
+    //  for the loads in flight where the paths join)
+    for (int k = 0; k < NR; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 28u * k * pitch, 0, 0);
     FC_STAMP(1);  // loads issued
     // meanwhile: clear the score tile and the row masks (16 bytes per lane and store), per-quad column masks
     const uint4 z4 = make_uint4(0, 0, 0, 0);
@@ -267,20 +270,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
       colmask[tid] = m;
     }
     FC_STAMP(2);  // clears
-    static_assert(NR == 18, "the wait below names every staged register");
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]),
-                   "+v"(v[17]));
-    // (the row count once more, opaque: otherwise the 18 row predicates of the load loop stay live in 36 scalar registers)
-    int nst2 = nst;
-    asm volatile("" : "+s"(nst2));
+    u32x4 *t4 = reinterpret_cast<u32x4 *>(tile) + row0 * 9 + c4, *q4 = reinterpret_cast<u32x4 *>(qtile) + row0 * 9 + c4;
 #pragma unroll
     for (int k = 0; k < NR; k++) {
-      const int r = wave + 4 * k;
-      if (r < nst2) {
-        tile[r * FC_TP + ln] = v[k];
-        qtile[r * FC_TP + ln] = quant6(v[k]);
+      if (row0 + 28 * k < nst) {
+        t4[28 * 9 * k] = v[k];
+        q4[28 * 9 * k] = (v[k] >> 2) & 0x3f3f3f3fu;
       }
     }
   }
