@@ -260,14 +260,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     for (int i = tid; i < (nrow + 2) * (FC_TP / 4); i += 256) reinterpret_cast<uint4 *>(stile)[i] = z4;
     if (tid < (nrow * FC_MAXK + 1) / 2) reinterpret_cast<uint4 *>(rmask)[tid] = z4;
     if (tid < 2) q_count[tid] = 0;  // [0] packed queue counts, [1] bit j: cell j falls back to minThFAST
-    if (tid < FC_TP) {
-      unsigned m = 0;
-#pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const int x = xs0 + 4 * tid + p;
-        if (x >= X0 && x <= X1) m |= 1u << (8 * p);
-      }
-      colmask[tid] = m;
+    if (tid < FC_TPB) {  // a byte (0 / 1) per tile column beyond the left apron: a thread per pixel, 36 quads
+      const int x = xs0 + tid;
+      reinterpret_cast<uint8_t *>(colmask)[tid] = (x >= X0 && x <= X1) ? 1 : 0;
     }
     FC_STAMP(2);  // clears
     u32x4 *t4 = reinterpret_cast<u32x4 *>(tile) + row0 * 9 + c4, *q4 = reinterpret_cast<u32x4 *>(qtile) + row0 * 9 + c4;
@@ -465,15 +460,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   const int j_a = __ffs(score_mask) - 1, j_b = min(31 - __clz(score_mask), (int)G.ncell - 1);
   const int qa_lo = (X0 + j_a * L.wcell - xs0) >> 2;
   const int nw_lo = ((min(X0 + (j_b + 1) * L.wcell - 1, X1) - xs0) >> 2) - qa_lo + 1;
-  if (tid < FC_TP) {
-    unsigned m = 0;
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const int rel = xs0 + 4 * tid + p - X0;
-      const int j = (rel >= L.wcell) + (rel >= 2 * L.wcell) + (rel >= 3 * L.wcell);
-      if (rel >= 0 && rel <= X1 - X0 && ((score_mask >> j) & 1u)) m |= 1u << (8 * p);
-    }
-    colmask[tid] = m;
+  if (tid < FC_TPB) {
+    const int rel = xs0 + tid - X0;
+    const int j = (rel >= L.wcell) + (rel >= 2 * L.wcell) + (rel >= 3 * L.wcell);
+    reinterpret_cast<uint8_t *>(colmask)[tid] = (rel >= 0 && rel <= X1 - X0 && ((score_mask >> j) & 1u)) ? 1 : 0;
   }
   __syncthreads();
   push_round(quick_round(qa_lo, nw_lo, std::true_type{}), true);
