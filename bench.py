@@ -467,17 +467,18 @@ def main():
                 "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P_fast * B, "traffic_source": traffic_src,
                 "avg_launch_ms_in_committed_rocprof_stats": rocprof_ms,
                 "avg_launch_ms_source": "live: HIP events on the kernel's stream around the launch (dispatch + the events' own "
-                                        "processing included, ~10 us more than the kernel itself); rocprof figure: "
+                                        "processing included, ~8 us more than the kernel itself); rocprof figure: "
                                         "profiles/r3_bench_no_large_kernel_stats.csv, valid for the default workload with "
                                         "level 0's launch beside the pyramid",
                 "launch": ("pyramid levels >= 1 of every frame, alone on the device; level 0's groups are a second launch of "
                            "the same kernel (k_fast_cells<false,1>, pipeline.fast_level0) that needs no pyramid and runs "
                            "beside the resize chain") if early_l0 else "all pyramid levels of every frame",
-                "limiter": "not HBM: the kernel (FAST score + per-cell NMS, fallback and compaction, fused) issues about one "
-                           "vector instruction per clock per CU, the measured ceiling of its mix "
-                           "(profiles/r3_hbm_traffic.json sq_counters_per_launch, profiles/r3_valu_rate.txt), and its time "
-                           "follows its occupancy (7-8 workgroups of seven barrier-separated phases per CU) and its "
-                           "instruction count about one to one (DESIGN.md, 'Tried and set aside in round 2')"}
+                "limiter": "not HBM (the counters show 0.96 x the algorithmic bytes, once): vector-instruction issue. The "
+                           "kernel (FAST score + per-cell NMS, fallback and compaction, fused) executes 1.05e8 wave "
+                           "instructions per launch on the vector ALU (round 2: 1.25e8; "
+                           "profiles/r3_hbm_traffic.json sq_counters_per_launch), and at the 4 clocks a SIMD needs for one "
+                           "wave64 instruction of this mix that alone is 0.19 ms at 2.2 GHz; the rest of a workgroup's 7.8 us "
+                           "is the latency of its tile load (DESIGN.md, 'Round 3: k_fast_cells')"}
     # whole extraction against SURVEY 8d's per-frame figure A = 5P - px0 - px7 + 1978 N
     A = 5 * P - g.w[0] * g.h[0] - g.w[g.levels - 1] * g.h[g.levels - 1] + 1978 * NF
     ext_s = st[6] * 1e-3
