@@ -146,8 +146,11 @@ __device__ unsigned fc_prof[FC_PROF_WG * 16];  // [workgroup][phase]: ticks; [15
     if (tid == 0 && prof_wg < FC_PROF_WG) fc_prof[prof_wg * 16 + (i)] = (unsigned)(t_now - t_prev); \
     t_prev = t_now;                                                                   \
   } while (0)
+__device__ volatile int fc_stop;  // phase after which every workgroup returns (0: never): instruction counts per phase under --pmc
+#define FC_STOP(n) do { if (fc_stop == (n)) return; } while (0)
 #else
 #define FC_STAMP(i) do { } while (0)
+#define FC_STOP(n) do { } while (0)
 #endif  // cells j0 .. j0 + ncell - 1 of cell row `row`
 
 constexpr int FC_TP = 36;               // dwords per staged / score row (<= 33 quads + 2 apron dwords)
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   FC_STAMP(3);  // set-up + staging issued
   __syncthreads();
   FC_STAMP(4);  // staging landed
+  FC_STOP(1);
 
   const int t_lo = g.fast_min, t_hi = g.fast_init;
   const int qcap = lds_rows * FC_QPITCH;
@@ -355,12 +359,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   {
     const QuickLane ql = quick_round(0, ncg, std::false_type{});
     FC_STAMP(5);  // quick-test passes
+    FC_STOP(2);
     __syncthreads();  // the queue takes the place of the quantised tile
     push_round(ql, false);
   }
   FC_STAMP(6);  // push
   __syncthreads();
   FC_STAMP(7);
+  FC_STOP(3);
   const int n_hi = *q_count & 0xffff;
   const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
   uint8_t *sb = reinterpret_cast<uint8_t *>(stile);
@@ -433,10 +439,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   FC_STAMP(8);  // full score
   __syncthreads();
   FC_STAMP(9);
+  FC_STOP(4);
   for (int q = tid; q < n_hi; q += 256) nms_entry(q, t_hi, 0xfu);
   FC_STAMP(10);  // NMS
   __syncthreads();
   FC_STAMP(11);
+  FC_STOP(5);
   if (wave < G.ncell) {
     // a cell without columns (beyond the last detection column) holds nothing at either threshold
     const bool has_cols = X0 + wave * L.wcell <= X1;
@@ -452,6 +460,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   FC_STAMP(12);  // emit
   __syncthreads();
   FC_STAMP(13);
+  FC_STOP(6);
   // ---- minThFAST for the cells that kept nothing (orb_feature_extractor.cpp:263-266: decided per cell AFTER NMS) ----
   const unsigned fallback = (unsigned)q_count[1];
   const unsigned score_mask = DUMP ? 0xfu : fallback;
@@ -513,6 +522,16 @@ void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, 
   const int first = part == 0 ? c->n_fast_groups_l0 : 0;
   const int count = part == 1 ? c->n_fast_groups_l0 : c->n_fast_groups - first;
   if (count <= 0) return;
+#ifdef ORBGPU_FAST_PROFILE
+  {
+    static int stop_set = -1;
+    if (stop_set < 0) {
+      const char *e = getenv("ORBGPU_FAST_STOP");
+      stop_set = e ? atoi(e) : 0;
+      if (hipMemcpyToSymbol(HIP_SYMBOL(fc_stop), &stop_set, sizeof(int)) != hipSuccess) fprintf(stderr, "fc_stop: copy failed\n");
+    }
+  }
+#endif
   const FastGroup *groups = reinterpret_cast<const FastGroup *>(c->d_fast_groups) + first;
   // dynamic LDS by the tallest cell of the launch's own levels: 32 rows (level 0 of a VGA frame) fit 8 workgroups per CU,
   // 33 rows and more only 7 -- and the kernel's time follows its occupancy
@@ -533,7 +552,7 @@ void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, 
     hipLaunchKernelGGL((k_fast_cells<false, 0>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
                        fs.n, slice_lvl0(c, fs), rows, (uint8_t *)nullptr);
 #ifdef ORBGPU_FAST_PROFILE
-  if (part != 1) {
+  if (part != 1 && !getenv("ORBGPU_FAST_STOP")) {
     static std::vector<unsigned> h(FC_PROF_WG * 16);
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fc_prof), h.size() * 4);

@@ -155,6 +155,12 @@ __device__ __forceinline__ unsigned mulhi24u(unsigned a, unsigned b) {
   asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// the same with a wave-uniform first factor straight from its scalar register
+__device__ __forceinline__ unsigned mulhi24u_s(unsigned a_uniform, unsigned b) {
+  unsigned d;
+  asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "s"(a_uniform), "v"(b));
+  return d;
+}
 
 __global__ __launch_bounds__(256) void k_resize_strips(uint8_t *__restrict__ pyr, DeviceGeom g, int level,
                                                        const XTab *__restrict__ xtab, const YTab *__restrict__ ytab,
@@ -189,13 +195,17 @@ __global__ __launch_bounds__(256) void k_resize_strips(uint8_t *__restrict__ pyr
     coef[p] = ((unsigned)X.a0 << 4) | ((unsigned)X.a1 << 20);  // (a0, a1) << 4 as u16 halves, each <= 32768
   }
   const int i0 = 4 * min(k0, 63), i1 = 4 * min(k0 + 1, 63), i2 = 4 * min(k0 + 2, 63);
-  const uint8_t *lsrc = src + 4 * min(sbase + lane, S.pitch / 4 - 1);
+  // buffer loads and stores: the level's first byte is the (scalar) base, the row's offset is scalar, the lane's column a
+  // 32-bit register -- no vector instruction per row for addresses
+  const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, S.h * S.pitch, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(dst, 0, D.h * D.pitch, 0x00020000);
+  const unsigned lcol = 4u * (unsigned)min(sbase + lane, S.pitch / 4 - 1);
   unsigned keep = 0;
 #pragma unroll
   for (int p = 0; p < 4; p++)
     if (dx + p < D.w) keep |= 0xffu << (8 * p);
   const bool writes = lane < nd;
-  uint8_t *ldst = dst + dx;
+  unsigned ooff = (unsigned)(y0 * D.pitch + dx);  // the lane's byte offset into the level, next output row
 
   const int y_end = min(y0 + __builtin_amdgcn_readfirstlane((int)st.w), D.h);
   const int sa = yt[y0].sy0, sb = yt[y_end - 1].sy1;
@@ -222,15 +232,16 @@ __global__ __launch_bounds__(256) void k_resize_strips(uint8_t *__restrict__ pyr
     const unsigned b0 = (unsigned)Y.b0 << 8, b1 = (unsigned)Y.b1 << 8;  // all coefficients are in [0, 2048]
     unsigned v[4];
 #pragma unroll
-    for (int p = 0; p < 4; p++) v[p] = mulhi24u(b0, h0[p]) + mulhi24u(b1, h1[p]) + 2u;  // <= 1022
+    for (int p = 0; p < 4; p++) v[p] = mulhi24u_s(b0, h0[p]) + mulhi24u_s(b1, h1[p]) + 2u;  // <= 1022
     const u16x2 lo = __builtin_bit_cast(u16x2, v[0] | (v[1] << 16)) >> 2, hi = __builtin_bit_cast(u16x2, v[2] | (v[3] << 16)) >> 2;
     const unsigned out = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x06040200u);
-    if (writes) *reinterpret_cast<unsigned *>(ldst + (size_t)y * D.pitch) = out & keep;
+    if (writes) __builtin_amdgcn_raw_buffer_store_b32(out & keep, rsrc_d, ooff, 0u, 0);
+    ooff += (unsigned)D.pitch;  // output rows are emitted in order
   };
   // source rows sa .. sb, 8 at a time, the next 8 in flight (rows beyond sb repeat sb: loaded, never used)
   auto load8 = [&](unsigned(&buf)[8], int s0) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) buf[k] = *reinterpret_cast<const unsigned *>(lsrc + (size_t)min(s0 + k, sb) * S.pitch);
+    for (int k = 0; k < 8; k++) buf[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, lcol, (unsigned)(min(s0 + k, sb) * S.pitch), 0);
   };
   auto chunk = [&](const unsigned(&cur)[8], unsigned(&nxt)[8], int s0) {
     if (s0 + 8 <= sb) load8(nxt, s0 + 8);
