@@ -153,6 +153,8 @@ def main():
                     help="skip the PCIe-inclusive host-pointer entry points (single-frame Extract, one window search, a "
                          "256-frame host batch); a profiled run skips them so that their launches are not averaged into the "
                          "per-kernel statistics of the batch kernels")
+    ap.add_argument("--one-context", action="store_true",
+                    help="skip the two-context section and feed the sequence section through one context (profiled runs)")
     ap.add_argument("--no-sequence", action="store_true", help="skip the offline sequence section (BASELINE configs[4])")
     ap.add_argument("--sequence-frames", type=int, default=20000,
                     help="frames of the offline sequence, sharded by block over the ranks (configs[4]: 20,000)")
@@ -309,6 +311,54 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
+    # ---- the same steps alternating between TWO contexts of the library (each with its own working buffers, streams and
+    # outputs): the tail of one batch -- descriptors and link, gathers that wait on memory -- then runs beside the head
+    # of the next -- pyramid and FAST, vector-ALU work.  Reported beside `value` (whose kernels run alone on the device,
+    # which is what the roofline figures need); the HBM-resident leg of the sequence section feeds its batches this way.
+    # The second context lives only for this section and for the HBM-resident leg of the sequence section: while it
+    # exists its streams share the process's 4 hardware queues with the upload stream of the PCIe-inclusive sections
+    # (measured: uploads fall from 42 to 31 GB/s).
+    def time_two_contexts():
+        if args.one_context:
+            return None
+        fe_b = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, device=local_rank, max_batch=B, max_features=NF)
+        b_kp, b_desc, b_n = torch.zeros_like(d_kp), torch.zeros_like(d_desc), torch.zeros_like(d_n)
+        b_match, b_dist, b_nm = torch.zeros_like(d_match), torch.zeros_like(d_dist), torch.zeros_like(d_nm)
+
+        def step_b():
+            for rc in (lib.orbgpu_extract_batch_device(fe_b.handle, d_imgs.data_ptr(), W * H, W, B, NF, b_kp.data_ptr(),
+                                                       b_desc.data_ptr(), cap, b_n.data_ptr()),
+                       lib.orbgpu_match_frames_device(fe_b.handle, b_kp.data_ptr(), b_desc.data_ptr(), b_n.data_ptr(), cap,
+                                                      d_to.data_ptr(), d_from.data_ptr(), n_pairs, 100, 50, 0.9, 1,
+                                                      b_match.data_ptr(), b_dist.data_ptr(), b_nm.data_ptr())
+                       if n_pairs > 0 else 0):
+                if rc != 0:
+                    raise RuntimeError(lib.orbgpu_last_error(fe_b.handle).decode())
+        for _ in range(3):
+            step()
+            step_b()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            (step_b if i & 1 else step)()
+        barrier()
+        dt2 = time.perf_counter() - t1
+        same = bool(torch.equal(d_n, b_n) and torch.equal(d_desc, b_desc) and torch.equal(d_match, b_match))
+        assert same, "the two contexts disagree"
+        t2 = torch.tensor([dt2], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        dt2 = float(t2.item())
+        fe_b.close()
+        return {
+            "frames_per_s": round(world * B * args.steps / dt2, 1), "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+            "steps": args.steps, "outputs_identical": same,
+            "what": "the timed loop's steps alternating between two contexts of the library on every GPU, each with its "
+                    "own working buffers, streams and output arrays: batch k + 1's pyramid and FAST run beside batch k's "
+                    "descriptors and link; max over ranks"}
+
+    two_contexts = time_two_contexts()
+
     # ---- SURVEY 8e / BASELINE.json configs[4]: cross-shard all-pairs keyframe matching -------------------------
     # every rank all-gathers the keyframe descriptor + keypoint shards (the path's ONE exchange step; RCCL when
     # N > 1) and matches its keyframes against all.  Reported beside the headline value, never part of it.
@@ -357,7 +407,10 @@ def main():
         legs = {}
         kf_result = None
         for leg, src in (("pcie_inclusive", pooled), ("hbm_resident", ResidentSource(pooled, dev))):
-            runner = SequenceRunner(fe, src, NF, keyframe_every=10)
+            # two contexts where the extraction is the bound (frames resident), one where PCIe is
+            two = leg == "hbm_resident" and not args.one_context
+            fe_b = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, device=local_rank, max_batch=B, max_features=NF) if two else None
+            runner = SequenceRunner([fe, fe_b] if two else fe, src, NF, keyframe_every=10)
             runner.run(min(n_seq, 3 * B), rank, world)            # warm-up: scratch, ring, events
             best = None
             for it in range(2):
@@ -372,12 +425,15 @@ def main():
             sec, res = best
             legs[leg] = {"seconds": round(sec, 4), "frames_per_s": round(n_seq / sec, 1),
                          "frames_extracted_rank0": res.timing["frames_extracted"], "batches_rank0": res.timing["batches"],
-                         "host_enqueue_seconds_rank0": round(res.timing["enqueue_seconds"], 4)}
+                         "host_enqueue_seconds_rank0": round(res.timing["enqueue_seconds"], 4),
+                         "contexts_per_rank": 2 if two else 1}
             if leg == "pcie_inclusive":
                 legs[leg]["upload_GBps_per_gpu"] = round(res.timing["bytes_uploaded"] / sec / 1e9, 2)
                 legs[leg]["source"] = "64 procedural frames in pinned host memory, frame i = pool[i % 64]; every frame crosses PCIe"
                 kf_result, kf_runner = res, runner
             del runner
+            if two:                                              # the sections below run with one context, as before
+                fe_b.close()
         # all-pairs over the keyframes of the PCIe leg's result: the popcount kernel (the contract path, the figures below),
         # then the same call on the exploratory i8 matrix-core engine, asserted identical
         barrier()
@@ -795,7 +851,7 @@ def main():
                       "link_matches_mean": round(float(n_matches.mean()), 1) if n_pairs else 0.0,
                       "parallelism": f"frame-sharded x{world}"},
            "roofline": roofline, "pipeline": pipeline, "matching": matching, "keyframe_allpairs": allpairs,
-           "sequence": sequence,
+           "two_contexts": two_contexts, "sequence": sequence,
            "keyframe_database": database, "host_pointer_path": host_path, "large_images": large,
            "projection_match": projection,
            "cpu_baseline": cpu}

@@ -11,7 +11,11 @@ frame-sharded offline job on MI355X:
   * every `keyframe_every`-th frame of the sequence is a keyframe: its keypoints and descriptors stay on the device for
     the cross-shard all-pairs matching (sharding.match_keyframes_allpairs: one all-gather, then rows x all columns);
   * uploads go through a ring of device image buffers on a copy stream of their own, ordered against the library's
-    stream with orbgpu_wait_event / orbgpu_record_event only, so batch k+1 crosses PCIe while batch k is extracted.
+    stream with orbgpu_wait_event / orbgpu_record_event only, so batch k+1 crosses PCIe while batch k is extracted;
+  * given TWO extractors (two contexts of the library, each with its own working buffers and streams) the batches
+    alternate between them, so that the tail of batch k (descriptors, link: gathers that wait on memory) runs beside the
+    head of batch k+1 (pyramid, FAST: vector-ALU work) -- 9 % more frames per second with the frames resident; the
+    carry of the last frame and the reuse of an output set are ordered with events between the two streams.
 
 Nothing here computes on the CPU; torch is used for device memory, streams and the device-side bookkeeping copies.
 """
@@ -105,13 +109,39 @@ class SequenceResult:
     timing: dict = field(default_factory=dict)
 
 
+class _OutputSet:
+    """what one context of the library works into: the output arrays of a batch (slot 0 = the frame carried over from
+    the previous batch, slots 1 .. B = this batch), the link results, the context's stream as a torch stream (the
+    device-side bookkeeping -- carry, keyframe gather, per-frame counts -- is enqueued on it between the library's calls,
+    so the stream itself orders everything a set holds) and two events for the hand-over between two sets"""
+
+    def __init__(self, lib, fe, B, cap, dev):
+        self.fe, self.h = fe, fe.handle
+        self.stream = torch.cuda.ExternalStream(int(lib.orbgpu_stream(fe.handle)), device=dev)
+        self.d_kp = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
+        self.d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
+        self.d_n = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        self.d_match = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+        self.d_dist = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+        self.d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.ev_extracted = torch.cuda.Event()   # this set's batch is extracted: its last frame may be carried over
+        self.ev_carried = torch.cuda.Event()     # the other set has taken its carry from this one: it may be overwritten
+        self.ev_carry_in = torch.cuda.Event()    # this set's slot 0 holds the carry of its current batch
+        self.ev_idle = torch.cuda.Event()        # this set's last batch is linked and gathered
+        for e in (self.ev_extracted, self.ev_carried, self.ev_carry_in, self.ev_idle):
+            e.record(self.stream)
+
+
 class SequenceRunner:
     """One rank's share of an offline sequence.  extractor: features.ORBFeatureExtractor created with max_batch = the
     batch size to walk in; source: a frame source (above).  ring: device image buffers in flight."""
 
     def __init__(self, extractor, source, feature_count, keyframe_every=10, window=100, threshold=50, ratio=0.9,
                  check_orientation=True, ring=4, copy_streams=1):
-        self.fe, self.src = extractor, source
+        # one extractor, or a list of two of the same configuration: batches alternate between them
+        self.fes = list(extractor) if isinstance(extractor, (list, tuple)) else [extractor]
+        self.fe, self.src = self.fes[0], source
+        extractor = self.fe
         self.lib = _lib.load()
         self.nf = int(feature_count)
         self.every = int(keyframe_every)
@@ -121,6 +151,10 @@ class SequenceRunner:
         if (self.W, self.H) != (extractor.image_width_, extractor.image_height_):
             raise _lib.OrbGpuError(_lib.E_INVALID, "frame source and extractor disagree on the image size")
         self.cap = extractor.geometry(self.nf).keypoint_capacity
+        for fe in self.fes[1:]:
+            if (fe.max_batch, fe.image_width_, fe.image_height_, fe._p.device, fe.geometry(self.nf).keypoint_capacity) != \
+                    (self.B, self.W, self.H, extractor._p.device, self.cap):
+                raise _lib.OrbGpuError(_lib.E_INVALID, "the extractors of a sequence runner must be configured alike")
         self.dev = torch.device("cuda", extractor._p.device)
         self.ring = max(2, int(ring))
         B, cap, dev = self.B, self.cap, self.dev
@@ -129,28 +163,20 @@ class SequenceRunner:
             self.copy_streams = [torch.cuda.Stream(self.dev) for _ in range(self.n_copy)]
             self.copy_stream = self.copy_streams[0]
             self.ev_join = [torch.cuda.Event() for _ in range(self.n_copy - 1)]
-            # the library's own stream as a torch stream: the device-side bookkeeping (carry, keyframe gather, per-frame
-            # counts) is enqueued on it between the library's calls, so the stream itself orders everything
-            self.lib_stream = torch.cuda.ExternalStream(int(self.lib.orbgpu_stream(extractor.handle)), device=self.dev)
             self.d_img = [torch.empty((B, self.H, self.W), dtype=torch.uint8, device=dev) for _ in range(self.ring)]
             self.h_img = None                      # pinned staging ring, only for sources without pinned runs
             self.ev_up = [torch.cuda.Event() for _ in range(self.ring)]     # upload of ring slot r has landed
             self.ev_free = [torch.cuda.Event() for _ in range(self.ring)]   # extraction of ring slot r has read it
             for e in self.ev_up + self.ev_free:
                 e.record(self.copy_stream)         # created by their first record (the library needs live handles)
-            # slot 0 = the frame carried over from the previous batch, slots 1 .. B = this batch
-            self.d_kp = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
-            self.d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
-            self.d_n = torch.zeros(B + 1, dtype=torch.int32, device=dev)
             self.d_to = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
             self.d_from = torch.arange(0, B, dtype=torch.int32, device=dev)
-            self.d_match = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-            self.d_dist = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-            self.d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.sets = [_OutputSet(self.lib, fe, B, cap, dev) for fe in self.fes]
+            self.carry_stream = torch.cuda.Stream(self.dev) if len(self.sets) > 1 else None
             torch.cuda.synchronize(self.dev)
 
-    def _check(self, rc):
-        _lib.check(rc, self.fe.handle)
+    def _check(self, rc, handle=None):
+        _lib.check(rc, handle if handle is not None else self.fe.handle)
 
     def _upload(self, k, first, count):
         """batch k (frames first .. first + count - 1) into ring slot k % ring, on the copy stream(s)"""
@@ -190,7 +216,7 @@ class SequenceRunner:
     def run(self, n_frames, rank=0, world=1, keep_links=False, keep_features=False):
         """Extract + link this rank's block of an n_frames sequence; returns a SequenceResult (per-frame arrays on the
         host, keyframes on the device).  Host-side work per batch is enqueue-only; the one wait is at the end."""
-        lib, h = self.lib, self.fe.handle
+        lib = self.lib
         B, cap, dev, nf = self.B, self.cap, self.dev, self.nf
         blk = frame_block(n_frames, world, rank)
         kf_ids = keyframe_ids(blk, self.every)
@@ -215,52 +241,79 @@ class SequenceRunner:
         for k in range(ahead):
             bytes_up += self._upload(k, batches[k][0], batches[k][1] - batches[k][0])
         kf_pos = 0
+        prev = None                                            # the set that holds the previous batch
         for k, (g0, g1) in enumerate(batches):
             c = g1 - g0
             r = k % self.ring
+            S = self.sets[k % len(self.sets)]
+            h = S.h
             if k + ahead < len(batches):
                 nb = batches[k + ahead]
                 bytes_up += self._upload(k + ahead, nb[0], nb[1] - nb[0])
-            self._check(lib.orbgpu_wait_event(h, self.ev_up[r].cuda_event))
+            self._check(lib.orbgpu_wait_event(h, self.ev_up[r].cuda_event), h)
+            if prev is not None and prev is not S:
+                # this set's arrays are overwritten now: the batch after its last one must have taken its carry
+                self._check(lib.orbgpu_wait_event(h, S.ev_carried.cuda_event), h)
             self._check(lib.orbgpu_extract_batch_device(h, self.d_img[r].data_ptr(), self.H * self.W, self.W, c, nf,
-                                                        self.d_kp[1].data_ptr(), self.d_desc[1].data_ptr(), cap,
-                                                        self.d_n[1:].data_ptr()))
-            self._check(lib.orbgpu_record_event(h, self.ev_free[r].cuda_event))
+                                                        S.d_kp[1].data_ptr(), S.d_desc[1].data_ptr(), cap,
+                                                        S.d_n[1:].data_ptr()), h)
+            self._check(lib.orbgpu_record_event(h, self.ev_free[r].cuda_event), h)
+            with torch.cuda.stream(S.stream):
+                S.ev_extracted.record(S.stream)
+            if prev is not None and prev is not S:
+                # carry across the two sets: the last frame of the previous batch is 'from' of this batch's first link.
+                # On a stream of its own, so that it runs as soon as the previous batch is extracted: on this set's
+                # stream it would sit behind this batch's extraction, and the other set's next extraction -- which
+                # overwrites what is carried -- behind that
+                cs = self.carry_stream
+                with torch.cuda.stream(cs):
+                    cs.wait_event(prev.ev_extracted)
+                    cs.wait_event(S.ev_idle)       # this set's last batch has read its slot 0
+                    S.d_kp[0].copy_(prev.d_kp[prev_c])
+                    S.d_desc[0].copy_(prev.d_desc[prev_c])
+                    S.d_n[0:1].copy_(prev.d_n[prev_c:prev_c + 1])
+                    prev.ev_carried.record(cs)
+                    S.ev_carry_in.record(cs)
+                S.stream.wait_event(S.ev_carry_in)
             # links: slot i -> slot i - 1.  The first batch has nothing in slot 0 (frame 0 of the sequence has no
             # predecessor; a halo frame is not owned), so its first pair is skipped
             p0 = 1 if k == 0 else 0
             if c - p0 > 0:
                 self._check(lib.orbgpu_match_frames_device(
-                    h, self.d_kp.data_ptr(), self.d_desc.data_ptr(), self.d_n.data_ptr(), cap, self.d_to[p0:].data_ptr(),
-                    self.d_from[p0:].data_ptr(), c - p0, window, th, ratio, co, self.d_match[p0:].data_ptr(),
-                    self.d_dist[p0:].data_ptr(), self.d_nm[p0:].data_ptr()))
+                    h, S.d_kp.data_ptr(), S.d_desc.data_ptr(), S.d_n.data_ptr(), cap, self.d_to[p0:].data_ptr(),
+                    self.d_from[p0:].data_ptr(), c - p0, window, th, ratio, co, S.d_match[p0:].data_ptr(),
+                    S.d_dist[p0:].data_ptr(), S.d_nm[p0:].data_ptr()), h)
             o = g0 - blk.halo_start
-            with torch.cuda.stream(self.lib_stream):
-                all_n[o:o + c].copy_(self.d_n[1:c + 1])
+            with torch.cuda.stream(S.stream):
+                all_n[o:o + c].copy_(S.d_n[1:c + 1])
                 if c - p0 > 0:
-                    all_nm[o + p0:o + c].copy_(self.d_nm[p0:c])
+                    all_nm[o + p0:o + c].copy_(S.d_nm[p0:c])
                     if keep_links:
-                        all_links[o + p0:o + c].copy_(self.d_match[p0:c])
+                        all_links[o + p0:o + c].copy_(S.d_match[p0:c])
                 if keep_features:
-                    all_kp[o:o + c].copy_(self.d_kp[1:c + 1])
-                    all_desc[o:o + c].copy_(self.d_desc[1:c + 1])
+                    all_kp[o:o + c].copy_(S.d_kp[1:c + 1])
+                    all_desc[o:o + c].copy_(S.d_desc[1:c + 1])
                 k1 = kf_pos
                 while k1 < K and kf_ids[k1] < g1:
                     k1 += 1
                 if k1 > kf_pos:                                # keyframes of this batch: slots of a regular stride
                     s0 = kf_ids[kf_pos] - g0 + 1
                     sl = slice(s0, s0 + (k1 - kf_pos - 1) * self.every + 1, self.every)
-                    kf_kp[kf_pos:k1].copy_(self.d_kp[sl])
-                    kf_desc[kf_pos:k1].copy_(self.d_desc[sl])
-                    kf_n[kf_pos:k1].copy_(self.d_n[sl])
+                    kf_kp[kf_pos:k1].copy_(S.d_kp[sl])
+                    kf_desc[kf_pos:k1].copy_(S.d_desc[sl])
+                    kf_n[kf_pos:k1].copy_(S.d_n[sl])
                     kf_pos = k1
-                # carry: the last frame of this batch is 'from' of the next batch's first link
-                self.d_kp[0].copy_(self.d_kp[c])
-                self.d_desc[0].copy_(self.d_desc[c])
-                self.d_n[0:1].copy_(self.d_n[c:c + 1])
+                if len(self.sets) == 1:
+                    # carry inside the one set: the last frame of this batch is 'from' of the next batch's first link
+                    S.d_kp[0].copy_(S.d_kp[c])
+                    S.d_desc[0].copy_(S.d_desc[c])
+                    S.d_n[0:1].copy_(S.d_n[c:c + 1])
+                S.ev_idle.record(S.stream)
+            prev, prev_c = S, c
         t_enq = time.perf_counter() - t0
-        self._check(lib.orbgpu_synchronize(h))                 # also surfaces device-side capacity errors
-        for st in self.copy_streams:
+        for S in self.sets:
+            self._check(lib.orbgpu_synchronize(S.h), S.h)      # also surfaces device-side capacity errors
+        for st in self.copy_streams + ([self.carry_stream] if self.carry_stream is not None else []):
             st.synchronize()
         t_all = time.perf_counter() - t0
         res = SequenceResult(

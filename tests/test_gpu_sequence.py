@@ -189,3 +189,38 @@ def test_sequence_pooled_and_resident_sources(runner):
     same = np.array_equal(a.links[5], a.links[29])
     assert same and a.n_links[5] > 100
     assert a.timing["bytes_uploaded"] == 300 * W * H
+
+
+def test_two_contexts_alternating(runner):
+    """batches alternating between two contexts of the library (the throughput arrangement of bench.py: the tail of a
+    batch beside the head of the next): per-frame counts, links across every batch boundary (the carry crosses the two
+    output sets), features and keyframes equal the one-context run's, with a partial last batch"""
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    from orb_slam3_amd.sequence import PooledSource, SequenceRunner
+    pool = PooledSource(91, pool_frames=40, height=H, width=W)
+    fe_b = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, max_batch=B, max_features=NF)
+    n = 3 * B + 77
+    one = SequenceRunner(runner.fe, pool, NF, keyframe_every=EVERY).run(n, keep_links=True, keep_features=True)
+    two_runner = SequenceRunner([runner.fe, fe_b], pool, NF, keyframe_every=EVERY)
+    for rep in range(2):  # the second run starts on sets that hold the first run's last batches
+        two = two_runner.run(n, keep_links=True, keep_features=True)
+        assert np.array_equal(one.n_keypoints, two.n_keypoints) and np.array_equal(one.n_links, two.n_links)
+        assert np.array_equal(one.links, two.links)
+        for f in range(n):  # rows beyond a frame's count hold whatever the output set held before
+            c = one.n_keypoints[f]
+            same = np.array_equal(one.descriptors[f, :c], two.descriptors[f, :c]) and np.array_equal(one.keypoints[f, :c], two.keypoints[f, :c])
+            assert same, f"frame {f}"
+        assert one.keyframe_ids == two.keyframe_ids
+        assert bool((one.kf_n == two.kf_n).all())
+        kn = one.kf_n.cpu().numpy()
+        a_d, b_d, a_k, b_k = one.kf_desc.cpu().numpy(), two.kf_desc.cpu().numpy(), one.kf_kp.cpu().numpy(), two.kf_kp.cpu().numpy()
+        for q in range(len(kn)):
+            same = np.array_equal(a_d[q, :kn[q]], b_d[q, :kn[q]]) and np.array_equal(a_k[q, :kn[q]], b_k[q, :kn[q]])
+            assert same, f"keyframe {q}"
+    for b in (B, 2 * B, 3 * B):  # the links into the first frame of a batch come from the other context's outputs
+        assert one.n_links[b] > 50
+    # 2 ranks, two contexts each: the block + halo arithmetic is untouched
+    parts = [two_runner.run(n, rank=r, world=2, keep_links=True) for r in range(2)]
+    assert np.array_equal(np.concatenate([p.n_links for p in parts]), one.n_links)
+    assert np.array_equal(np.concatenate([p.links for p in parts]), one.links)
+    fe_b.close()

@@ -11,9 +11,9 @@ echo trace done
 # the same without the large-image, sequence and host-path sections (their launches of the same kernels run on other
 # batch sizes): there every k_fast_cells launch is a headline launch, so the kernel's average
 # in this file is the one the bench line's roofline.avg_launch_ms has to agree with
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_no_large --output-format csv -- python3 bench.py --no-large --no-sequence --no-host-path > $OUT/bench_no_large_under_trace.json 2> $OUT/trace_no_large.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_no_large --output-format csv -- python3 bench.py --no-large --no-sequence --no-host-path --one-context > $OUT/bench_no_large_under_trace.json 2> $OUT/trace_no_large.log
 echo trace without large images done
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bruteforce --no-database --no-large --no-projection --no-allpairs --no-sequence --no-host-path"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bruteforce --no-database --no-large --no-projection --no-allpairs --no-sequence --no-host-path --one-context"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- $BENCH > $OUT/pmc_fetch.log 2>&1
 echo fetch done
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write --output-format csv -- $BENCH > $OUT/pmc_write.log 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench of the headline + large-image sections only.  Usage: tools/quick_large_bench.sh [env assignments...]
 set -o pipefail
-timeout -k 10 200 env "$@" python bench.py --no-cpu-baseline --no-bruteforce --no-database --no-allpairs --no-projection --no-sequence --no-host-path --steps 10 --warmup 3 > gpurun_out/ql_b.json 2> gpurun_out/ql_b.err || { tail gpurun_out/ql_b.err; exit 1; }
+timeout -k 10 200 env "$@" python bench.py --no-cpu-baseline --no-bruteforce --no-database --no-allpairs --no-projection --no-sequence --no-host-path --one-context --steps 10 --warmup 3 > gpurun_out/ql_b.json 2> gpurun_out/ql_b.err || { tail gpurun_out/ql_b.err; exit 1; }
 python3 - <<'P'
 import json
 d = json.load(open("gpurun_out/ql_b.json"))
