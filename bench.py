@@ -495,7 +495,13 @@ def main():
     # when level 0 has its own launch beside the pyramid) x frames per launch
     fast_s = st[1] * 1e-3
     hbm_peak = 8000.0
-    P_fast = P - g.w[0] * g.h[0] if early_l0 else P
+    # levels of the launch on the critical path: all but level 0 by default (ORBGPU_TUNE=early_levels=E moves the first E
+    # levels to the second stream)
+    n_early = 0
+    if early_l0:
+        tune = dict(kv.split("=", 1) for kv in os.environ.get("ORBGPU_TUNE", "").split(";") if "=" in kv)
+        n_early = max(1, min(3, int(tune.get("early_levels", "1")), g.levels - 1))
+    P_fast = P - sum(g.w[l] * g.h[l] for l in range(n_early))
     fast_kernel = "k_fast_cells<false,0>" if early_l0 else "k_fast_cells"
     fast_gbs = P_fast * B / fast_s / 1e9 if fast_s > 0 else 0.0
     # HBM-side bytes per launch from the committed counter passes (tools/profile_round.sh -> profiles/): valid for the
@@ -526,7 +532,7 @@ def main():
                                         "processing included, ~8 us more than the kernel itself); rocprof figure: "
                                         "profiles/r3_bench_no_large_kernel_stats.csv, valid for the default workload with "
                                         "level 0's launch beside the pyramid",
-                "launch": ("pyramid levels >= 1 of every frame, alone on the device; level 0's groups are a second launch of "
+                "launch": (f"pyramid levels >= {n_early} of every frame, alone on the device; level 0's groups are a second launch of "
                            "the same kernel (k_fast_cells<false,1>, pipeline.fast_level0) that needs no pyramid and runs "
                            "beside the resize chain") if early_l0 else "all pyramid levels of every frame",
                 "limiter": "not HBM (the counters show 0.96 x the algorithmic bytes, once): vector-instruction issue. The "

@@ -291,21 +291,30 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     const bool timed = s == 0 && stage_timing;       // the stage timers follow slice 0
     const bool timed_fast = s == 0 && !capture;      // the FAST kernel (the roofline kernel) is always bracketed
     if (s > 0) HIP_TRY(hipStreamWaitEvent(fs.stream, ev[0], 0));  // fork: after everything already on the context's stream
-    const bool early = ctx->early_l0;
-    if (early) {  // level 0 needs no pyramid: its FAST groups on a stream of their own, beside the resize chain
-      const FrameSlice fl{f0, f1 - f0, ctx->no_overlap ? fs.stream : ctx->slice_l0[s]};
+    // FAST of the first E levels on a stream of their own beside the resize chain, each as soon as its level exists
+    // (level 0 needs no pyramid at all); the launch on the critical path covers the levels from E on
+    const int E = ctx->early_l0 ? std::min(ctx->early_levels, L - 1) : 0;
+    const FrameSlice fl{f0, f1 - f0, ctx->no_overlap ? fs.stream : ctx->slice_l0[s]};
+    if (E > 0) {
       HIP_TRY(hipEventRecord(sev[3], fs.stream));  // after everything already on the stream (the caller's images included)
       HIP_TRY(hipStreamWaitEvent(fl.stream, sev[3], 0));
       if (timed) HIP_TRY(hipEventRecord(ev[10], fl.stream));
-      launch_fast_cells(ctx, fl, nullptr, 1);
+      launch_fast_cells(ctx, fl, nullptr, 0, 1, true);
       if (timed) HIP_TRY(hipEventRecord(ev[11], fl.stream));
-      HIP_TRY(hipEventRecord(sev[4], fl.stream));
     }
-    for (int l = 1; l < L; l++) launch_pyramid_level(ctx, fs, l);
+    for (int l = 1; l < L; l++) {
+      launch_pyramid_level(ctx, fs, l);
+      if (l < E) {
+        HIP_TRY(hipEventRecord(sev[4 + l], fs.stream));
+        HIP_TRY(hipStreamWaitEvent(fl.stream, sev[4 + l], 0));
+        launch_fast_cells(ctx, fl, nullptr, l, l + 1, true);
+      }
+    }
+    if (E > 0) HIP_TRY(hipEventRecord(sev[4], fl.stream));
     if (timed_fast) HIP_TRY(hipEventRecord(ev[1], fs.stream));
-    launch_fast_cells(ctx, fs, nullptr, early ? 0 : -1);
+    launch_fast_cells(ctx, fs, nullptr, E, L, false);
     if (timed_fast) HIP_TRY(hipEventRecord(ev[2], fs.stream));
-    if (early) HIP_TRY(hipStreamWaitEvent(fs.stream, sev[4], 0));  // the quadtree needs every level's cells
+    if (E > 0) HIP_TRY(hipStreamWaitEvent(fs.stream, sev[4], 0));  // the quadtree needs every level's cells
     // the blur's fork point: the FAST kernel's end event when it has just been recorded (one event between two kernels
     // of the critical path instead of two)
     // patch mode (large images, few keypoints per pixel): no full-frame blur at all -- one kernel behind the quadtree takes
@@ -694,6 +703,10 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       ctx->n_fast_groups_l0 = 0;
       for (size_t q = 0; q < groups.size(); q += 4)
         if (groups[q] == 0) ctx->n_fast_groups_l0++;
+      for (int l = 0; l <= g.levels; l++) ctx->fast_group_first[l] = 0;
+      for (size_t q = 0; q < groups.size(); q += 4)
+        for (int l = groups[q] + 1; l <= g.levels; l++) ctx->fast_group_first[l]++;
+      if (const char *el = orbgpu_tune("early_levels")) ctx->early_levels = std::max(1, std::min(3, atoi(el)));  // tuning aid
       const char *nov = orbgpu_tune("no_overlap");
       ctx->no_overlap = nov && nov[0] == '1';
       const char *el0 = orbgpu_tune("early_l0");
@@ -1005,7 +1018,7 @@ int orbgpu_debug_dump(orbgpu_ctx *ctx, int32_t frame, uint8_t *pyramid, uint8_t 
     // its DUMP switch, which scatters every non-zero score into a one-frame slab (allocated by the first such dump)
     if (!ctx->d_score) HIP_TRY(dmalloc(&ctx->d_score, (size_t)g.frame_bytes + 256));
     HIP_TRY(hipMemsetAsync(ctx->d_score, 0, g.frame_bytes, ctx->stream));
-    launch_fast_cells(ctx, FrameSlice{frame, 1, ctx->stream}, ctx->d_score);
+    launch_fast_cells(ctx, FrameSlice{frame, 1, ctx->stream}, ctx->d_score, 0, ctx->geom.levels, false);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }

@@ -516,11 +516,11 @@ int build_fast_groups(const DeviceGeom &g, std::vector<short> &table) {
   return (int)(table.size() / 4);
 }
 
-// part: -1 = every group in one launch, 0 = the groups of levels >= 1, 1 = the groups of level 0 (the table is level-major)
-void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, int part) {
+// the groups of the levels [la, lb) (the table is level-major); early: k_fast_cells<false, 1>, the launches beside the resize chain
+void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, int la, int lb, bool early) {
   const DeviceGeom &g = c->geom;
-  const int first = part == 0 ? c->n_fast_groups_l0 : 0;
-  const int count = part == 1 ? c->n_fast_groups_l0 : c->n_fast_groups - first;
+  const int first = c->fast_group_first[la];
+  const int count = c->fast_group_first[lb] - first;
   if (count <= 0) return;
 #ifdef ORBGPU_FAST_PROFILE
   {
@@ -536,7 +536,7 @@ void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, 
   // dynamic LDS by the tallest cell of the launch's own levels: 32 rows (level 0 of a VGA frame) fit 8 workgroups per CU,
   // 33 rows and more only 7 -- and the kernel's time follows its occupancy
   int rows = 0;
-  for (int l = (part == 0 ? 1 : 0); l < (part == 1 ? 1 : g.levels); l++) rows = std::max(rows, g.lv[l].hcell);
+  for (int l = la; l < lb; l++) rows = std::max(rows, g.lv[l].hcell);
   const size_t lds = fast_cells_lds_bytes(rows);
   dim3 grid(count * xcd_frames(fs.n));
   const uint8_t *pyr = c->d_pyr + (size_t)fs.f0 * g.frame_bytes;
@@ -545,14 +545,14 @@ void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, 
   if (score_dump)
     hipLaunchKernelGGL((k_fast_cells<true, 0>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
                        fs.n, slice_lvl0(c, fs), rows, score_dump);
-  else if (part == 1)
+  else if (early)
     hipLaunchKernelGGL((k_fast_cells<false, 1>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
                        fs.n, slice_lvl0(c, fs), rows, (uint8_t *)nullptr);
   else
     hipLaunchKernelGGL((k_fast_cells<false, 0>), grid, dim3(256), lds, fs.stream, pyr, g, groups, count, cells, cands,
                        fs.n, slice_lvl0(c, fs), rows, (uint8_t *)nullptr);
 #ifdef ORBGPU_FAST_PROFILE
-  if (part != 1 && !getenv("ORBGPU_FAST_STOP")) {
+  if (!early && !getenv("ORBGPU_FAST_STOP")) {
     static std::vector<unsigned> h(FC_PROF_WG * 16);
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(fc_prof), h.size() * 4);

@@ -111,7 +111,7 @@ struct orbgpu_ctx {
   hipStream_t slice_stream[MAX_SLICES]{};  // slices 1.. of a batch (slice 0 runs on `stream`)
   hipStream_t slice_l0[MAX_SLICES]{};      // level 0's FAST launch of a slice runs beside its resize chain
   hipStream_t slice_blur[MAX_SLICES]{};    // the blur of a slice runs beside its (latency-bound) quadtree kernel
-  hipEvent_t slice_ev[MAX_SLICES][5]{};    // fork / blur-may-start / slice-done
+  hipEvent_t slice_ev[MAX_SLICES][8]{};    // fork / blur-may-start / slice-done / level-0 fork and join / pyramid level l < early_levels done (5 ..)
   std::recursive_mutex mu;  // recursive: host-pointer entry points hold it while they call their *_device twins
   std::string err;
 
@@ -124,6 +124,8 @@ struct orbgpu_ctx {
   short *d_fast_groups = nullptr; // FastGroup table of k_fast_cells (level, cell row, first cell, cells), one frame's worth
   int n_fast_groups = 0;
   int n_fast_groups_l0 = 0;       // groups of level 0 (the table is level-major)
+  int fast_group_first[ORBGPU_MAX_LEVELS + 1] = {};  // first group of every level
+  int early_levels = 1;           // FAST of the levels below this on the second stream, each as soon as its level exists
   bool no_overlap = false;        // ORBGPU_NO_OVERLAP=1 (tuning aid): every kernel on the main stream, for stage times of kernels running alone
   bool early_l0 = true;           // level 0's FAST groups on the second stream beside the resize chain (ORBGPU_EARLY_L0=0: off)
   short *d_blur_strips = nullptr; // (level, first dword, first row, dwords) per strip of one frame (k_blur)
@@ -225,7 +227,8 @@ bool build_resize_nest(const DeviceGeom &g, const XTab *xt, const YTab *yt, int 
 // fused FAST score + cell NMS (k_fast.hip); score_dump != nullptr: also scatter the non-zero scores into that slab
 // (laid out like the slice: its frame 0 is frame f0 of the batch)
 int build_fast_groups(const DeviceGeom &g, std::vector<short> &table);
-void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, int part = -1);
+// levels [la, lb); early: the launch runs on the second stream beside the resize chain (a kernel name of its own)
+void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, int la, int lb, bool early);
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs);
 int build_blur_strips(const DeviceGeom &g, std::vector<short> &table);
 int build_resize_strips(const DeviceGeom &g, int level, const XTab *xt, std::vector<short> &table, int strip_target);

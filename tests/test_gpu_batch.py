@@ -353,7 +353,7 @@ def test_caller_stream_and_capacity_flag(oracle):
     fe.close()
 
 
-@pytest.mark.parametrize("switch", ["early_l0=0", "no_overlap=1", "resize=tiles", "slices=2", "qt_presort_minpx=0",
+@pytest.mark.parametrize("switch", ["early_l0=0", "early_levels=2", "early_levels=3", "no_overlap=1", "resize=tiles", "slices=2", "qt_presort_minpx=0",
                                     "qt_presort_minpx=0;slices=2", "qt_presort_minpx=0;ps_blur=early",
                                     "resize_nest=4:3", "patch_blur=1"])
 def test_schedules_give_identical_results(monkeypatch, switch):
