@@ -406,7 +406,10 @@ def main():
         pooled = PooledSource(1240, pool_frames=min(64, max(B, 8)), height=H, width=W)
         legs = {}
         kf_result = None
-        for leg, src in (("pcie_inclusive", pooled), ("hbm_resident", ResidentSource(pooled, dev))):
+        # resident leg: the same frames (frame i = pool[i % 64]) tiled to a batch's length on the device, so that a batch
+        # that starts on a multiple of the batch size is one slice and is extracted in place
+        resident = ResidentSource(pooled, dev, repeat=max(1, B // pooled.pool.shape[0]))
+        for leg, src in (("pcie_inclusive", pooled), ("hbm_resident", resident)):
             # two contexts where the extraction is the bound (frames resident), one where PCIe is
             two = leg == "hbm_resident" and not args.one_context
             fe_b = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, device=local_rank, max_batch=B, max_features=NF) if two else None

@@ -78,17 +78,21 @@ class PooledSource:
 
     def fill(self, first, count, out):
         for k in range(count):
-            out[k] = self.frames[self.index(first + k)]
+            out[k] = self.frames[(first + k) % len(self.frames)]
 
 
 class ResidentSource(PooledSource):
     """The same pool already resident in HBM: the 'inputs already on the device' leg of the measurement (what `value`
     of bench.py assumes); a batch is a device-to-device copy of pool slices."""
 
-    def __init__(self, pooled, device):
+    def __init__(self, pooled, device, repeat=1):
+        # repeat: the pool tiled that many times on the device (frame i is still pool frame i % len(pool)), so that a
+        # whole batch can be one contiguous slice -- which the runner then extracts in place, without a copy
         self.height, self.width = pooled.height, pooled.width
         self.frames = pooled.frames
         self.pool = pooled.pool.to(device)
+        if repeat > 1:
+            self.pool = torch.cat([self.pool] * int(repeat))
 
 
 # ---------------------------------------------------------------------------------------------- results
@@ -124,11 +128,9 @@ class _OutputSet:
         self.d_match = torch.zeros((B, cap), dtype=torch.int32, device=dev)
         self.d_dist = torch.zeros((B, cap), dtype=torch.int32, device=dev)
         self.d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.ev_extracted = torch.cuda.Event()   # this set's batch is extracted: its last frame may be carried over
-        self.ev_carried = torch.cuda.Event()     # the other set has taken its carry from this one: it may be overwritten
-        self.ev_carry_in = torch.cuda.Event()    # this set's slot 0 holds the carry of its current batch
+        self.ev_carry_in = torch.cuda.Event()    # this set's slot 0 holds the carry for its next batch
         self.ev_idle = torch.cuda.Event()        # this set's last batch is linked and gathered
-        for e in (self.ev_extracted, self.ev_carried, self.ev_carry_in, self.ev_idle):
+        for e in (self.ev_carry_in, self.ev_idle):
             e.record(self.stream)
 
 
@@ -165,6 +167,7 @@ class SequenceRunner:
             self.ev_join = [torch.cuda.Event() for _ in range(self.n_copy - 1)]
             self.d_img = [torch.empty((B, self.H, self.W), dtype=torch.uint8, device=dev) for _ in range(self.ring)]
             self.h_img = None                      # pinned staging ring, only for sources without pinned runs
+            self.batch_in = list(self.d_img)       # what the extraction of ring slot r reads: the slot, or the source's own memory
             self.ev_up = [torch.cuda.Event() for _ in range(self.ring)]     # upload of ring slot r has landed
             self.ev_free = [torch.cuda.Event() for _ in range(self.ring)]   # extraction of ring slot r has read it
             for e in self.ev_up + self.ev_free:
@@ -172,7 +175,6 @@ class SequenceRunner:
             self.d_to = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
             self.d_from = torch.arange(0, B, dtype=torch.int32, device=dev)
             self.sets = [_OutputSet(self.lib, fe, B, cap, dev) for fe in self.fes]
-            self.carry_stream = torch.cuda.Stream(self.dev) if len(self.sets) > 1 else None
             torch.cuda.synchronize(self.dev)
 
     def _check(self, rc, handle=None):
@@ -184,6 +186,12 @@ class SequenceRunner:
         cs = self.copy_stream
         cs.wait_event(self.ev_free[r])             # the extraction that last read this slot has finished with it
         runs = self.src.runs(first, count)
+        if runs is not None and len(runs) == 1 and runs[0].is_cuda and runs[0].is_contiguous():
+            # the batch is one slice of device memory: extracted where it lies
+            self.batch_in[r] = runs[0]
+            self.ev_up[r].record(cs)
+            return 0
+        self.batch_in[r] = self.d_img[r]
         if runs is None:                           # host generator: fill a pinned staging slot, then one copy
             if self.h_img is None:
                 self.h_img = [torch.empty((self.B, self.H, self.W), dtype=torch.uint8).pin_memory()
@@ -241,7 +249,6 @@ class SequenceRunner:
         for k in range(ahead):
             bytes_up += self._upload(k, batches[k][0], batches[k][1] - batches[k][0])
         kf_pos = 0
-        prev = None                                            # the set that holds the previous batch
         for k, (g0, g1) in enumerate(batches):
             c = g1 - g0
             r = k % self.ring
@@ -251,29 +258,24 @@ class SequenceRunner:
                 nb = batches[k + ahead]
                 bytes_up += self._upload(k + ahead, nb[0], nb[1] - nb[0])
             self._check(lib.orbgpu_wait_event(h, self.ev_up[r].cuda_event), h)
-            if prev is not None and prev is not S:
-                # this set's arrays are overwritten now: the batch after its last one must have taken its carry
-                self._check(lib.orbgpu_wait_event(h, S.ev_carried.cuda_event), h)
-            self._check(lib.orbgpu_extract_batch_device(h, self.d_img[r].data_ptr(), self.H * self.W, self.W, c, nf,
+            self._check(lib.orbgpu_extract_batch_device(h, self.batch_in[r].data_ptr(), self.H * self.W, self.W, c, nf,
                                                         S.d_kp[1].data_ptr(), S.d_desc[1].data_ptr(), cap,
                                                         S.d_n[1:].data_ptr()), h)
             self._check(lib.orbgpu_record_event(h, self.ev_free[r].cuda_event), h)
-            with torch.cuda.stream(S.stream):
-                S.ev_extracted.record(S.stream)
-            if prev is not None and prev is not S:
-                # carry across the two sets: the last frame of the previous batch is 'from' of this batch's first link.
-                # On a stream of its own, so that it runs as soon as the previous batch is extracted: on this set's
-                # stream it would sit behind this batch's extraction, and the other set's next extraction -- which
-                # overwrites what is carried -- behind that
-                cs = self.carry_stream
-                with torch.cuda.stream(cs):
-                    cs.wait_event(prev.ev_extracted)
-                    cs.wait_event(S.ev_idle)       # this set's last batch has read its slot 0
-                    S.d_kp[0].copy_(prev.d_kp[prev_c])
-                    S.d_desc[0].copy_(prev.d_desc[prev_c])
-                    S.d_n[0:1].copy_(prev.d_n[prev_c:prev_c + 1])
-                    prev.ev_carried.record(cs)
-                    S.ev_carry_in.record(cs)
+            two = len(self.sets) > 1
+            if two and k + 1 < len(batches):
+                # carry across the two sets: the last frame of this batch is 'from' of the next batch's first link, which
+                # the OTHER context computes.  Pushed from this set's stream right behind the extraction (no stream of
+                # its own: every stream that waits shares one of the process's 4 hardware queues with others and holds
+                # them up); the other set's slot 0 is free once its last batch is linked and gathered
+                N = self.sets[(k + 1) % len(self.sets)]
+                with torch.cuda.stream(S.stream):
+                    S.stream.wait_event(N.ev_idle)
+                    N.d_kp[0].copy_(S.d_kp[c])
+                    N.d_desc[0].copy_(S.d_desc[c])
+                    N.d_n[0:1].copy_(S.d_n[c:c + 1])
+                    N.ev_carry_in.record(S.stream)
+            if two and k > 0:
                 S.stream.wait_event(S.ev_carry_in)
             # links: slot i -> slot i - 1.  The first batch has nothing in slot 0 (frame 0 of the sequence has no
             # predecessor; a halo frame is not owned), so its first pair is skipped
@@ -309,11 +311,10 @@ class SequenceRunner:
                     S.d_desc[0].copy_(S.d_desc[c])
                     S.d_n[0:1].copy_(S.d_n[c:c + 1])
                 S.ev_idle.record(S.stream)
-            prev, prev_c = S, c
         t_enq = time.perf_counter() - t0
         for S in self.sets:
             self._check(lib.orbgpu_synchronize(S.h), S.h)      # also surfaces device-side capacity errors
-        for st in self.copy_streams + ([self.carry_stream] if self.carry_stream is not None else []):
+        for st in self.copy_streams:
             st.synchronize()
         t_all = time.perf_counter() - t0
         res = SequenceResult(

@@ -172,10 +172,12 @@ def test_sequence_pooled_and_resident_sources(runner):
     fe = runner.fe
     pool = PooledSource(77, pool_frames=24, height=H, width=W)
     out = []
-    for src in (pool, ResidentSource(pool, runner.dev)):
+    for src in (pool, ResidentSource(pool, runner.dev), ResidentSource(pool, runner.dev, repeat=11)):  # the last: batches extracted in place
         r = SequenceRunner(fe, src, NF, keyframe_every=EVERY)
         out.append(r.run(300, keep_links=True, keep_features=True))
-    a, b = out
+    a, b, c_ = out
+    assert np.array_equal(a.n_keypoints, c_.n_keypoints) and np.array_equal(a.n_links, c_.n_links) and np.array_equal(a.links, c_.links)
+    assert c_.timing["bytes_uploaded"] < 300 * W * H  # 24 x 11 = 264 frames: the first batch of 256 is one slice
     assert np.array_equal(a.n_keypoints, b.n_keypoints) and np.array_equal(a.n_links, b.n_links)
     for f in range(300):
         c = a.n_keypoints[f]
