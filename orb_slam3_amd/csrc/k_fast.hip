@@ -122,21 +122,23 @@ __device__ __forceinline__ unsigned quick_quad(const unsigned *tw, unsigned ka, 
 // blind across cell seams and a workgroup that owns whole cells needs nothing from its neighbours.
 // A workgroup takes one "group": up to 4 horizontally adjacent cells of one cell row (<= 128 pixels wide, <= 64 rows),
 // stages the pixels of their detection rectangles plus the 3-pixel ring apron, and keeps every intermediate in LDS:
-//   phase 1  quick test on pixel PAIRS in packed u16 (4 opposite ring pairs), 4 pixels x 1 row per lane and pass, the
-//            group's quads (4-pixel columns x rows) dealt out flat so that no lane idles whatever the cell geometry;
-//            candidate flags come from saturating packed arithmetic, no compares;
-//   push     survivors -> LDS queue, one LDS atomic per wave;
+//   stage    the tile with 16-byte buffer loads, once raw and once quantised to 6 bits per pixel;
+//   phase 1  quick test at iniThFAST on bytes (quick_quad: 4 pixels per operation on the quantised tile, conservative),
+//            a lane keeps its quad column and walks down the rows; survivor bits collect in a register;
+//   push     survivors -> LDS queue as (row, column), one wave scan + one LDS atomic per wave;
 //   phase 2  full 9-arc score per survivor -> score tile in LDS (zero apron);
 //   phase 3  3x3 NMS per scored pixel, neighbours outside the pixel's own cell masked; survivors set a bit in their
 //            cell's row mask, one mask for "kept" and one for "kept and >= iniThFAST";
-//   phase 4  one wave per cell: threshold fallback decided after NMS, survivors written in raster order to the cell's
-//            fixed slot of the candidate pool, CellEntry written.
+//   phase 4  one wave per cell: survivors written in raster order to the cell's fixed slot of the candidate pool;
+//   then, only if a cell kept nothing (orb_feature_extractor.cpp:263-266: decided per cell AFTER NMS): a second quick
+//            test at minThFAST over the columns of those cells, score, NMS and emit for them.
 // No score map, no bit plane and no second kernel: the only global traffic is the tile read and the candidates.
 // DUMP = true additionally scatters the non-zero scores into a global score map (orbgpu_debug_dump's stage test).
 struct FastGroup { short level, row, j0, ncell; };
 
 // -DORBGPU_FAST_PROFILE (debugging aid, never in the shipped library): wave 0 of every workgroup adds the 100 MHz
-// clock ticks it spent in each phase to fc_prof[phase], the launch prints the means
+// clock ticks it spent in each phase into its own slot of fc_prof, the launch prints the means; ORBGPU_FAST_STOP=n makes
+// every workgroup return after phase n (instruction counts per phase under rocprofv3 --pmc, tools/fast_phase_counts.sh)
 #ifdef ORBGPU_FAST_PROFILE
 constexpr int FC_PROF_WG = 65536;
 __device__ unsigned fc_prof[FC_PROF_WG * 16];  // [workgroup][phase]: ticks; [15]: 1 + (took the minThFAST round)
