@@ -90,6 +90,19 @@ int orbgpu_get_geometry(const orbgpu_ctx *ctx, int32_t feature_count, orbgpu_geo
  * synchronisation of that stream before a *_device call and orbgpu_synchronize before reading the results. */
 void *orbgpu_stream(orbgpu_ctx *ctx);
 int orbgpu_synchronize(orbgpu_ctx *ctx);
+/* no counterpart in the reference (a scheduling hint for callers that feed batch after batch; results and their order
+ * on the context's stream are unchanged).
+ * By default the kernels of an extract call start behind everything already enqueued on the context's stream -- which is
+ * also how they see the caller's images.  With ready != 0 the caller promises that the images of every later
+ * orbgpu_extract_batch_device call are complete when the call is made, or, with a non-null `event` (a hipEvent_t), when
+ * that event has fired (call this before each extract to name the batch's own event).  The library then runs the call's
+ * pyramid and FAST kernels on a stream of its own as soon as the previous call has read its pyramid for the last time --
+ * beside the previous batch's descriptor kernel and whatever the caller enqueued behind it (the link) -- and keeps
+ * everything from the quadtree on, and so the outputs, in the context's stream order.  Applies to images that are
+ * read in place (orbgpu_extract_batch_device's layout rule) with the full-frame blur; other calls run as before.
+ * ready == 0 (the default) restores the plain stream order. */
+int orbgpu_set_input_ready(orbgpu_ctx *ctx, int32_t ready, void *event);
+
 /* No counterpart in the reference.  Waits for the context's work (like orbgpu_synchronize, whose status it returns) and
  * releases the side streams an extract call forks onto (level 0's FAST launch, the blur, batch slices) together with
  * their events; the next extract call re-creates the ones it needs.  A process maps all its streams onto 4 hardware

@@ -68,7 +68,7 @@ assert KP_DTYPE.itemsize == 32
 
 # every symbol include/orbgpu.h declares (the inline orbgpu_hamming256 aside)
 EXPORTS = ["orbgpu_create", "orbgpu_destroy", "orbgpu_last_error", "orbgpu_get_geometry", "orbgpu_stream",
-           "orbgpu_synchronize", "orbgpu_trim", "orbgpu_set_stream", "orbgpu_set_batch_slices", "orbgpu_wait_event", "orbgpu_record_event", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
+           "orbgpu_synchronize", "orbgpu_trim", "orbgpu_set_input_ready", "orbgpu_set_stream", "orbgpu_set_batch_slices", "orbgpu_wait_event", "orbgpu_record_event", "orbgpu_extract", "orbgpu_extract_batch", "orbgpu_extract_batch_device",
            "orbgpu_debug_dump", "orbgpu_match_bruteforce", "orbgpu_match_bruteforce_device", "orbgpu_match_bruteforce_noalloc_device", "orbgpu_set_bruteforce_engine",
            "orbgpu_match_window",
            "orbgpu_match_window_device", "orbgpu_match_window_segments_device", "orbgpu_grid_build_device",
@@ -104,6 +104,7 @@ def load():
         "orbgpu_stream": (vp, [vp]),
         "orbgpu_synchronize": (i32, [vp]),
         "orbgpu_trim": (i32, [vp]),
+        "orbgpu_set_input_ready": (i32, [vp, i32, vp]),
         "orbgpu_set_stream": (i32, [vp, vp]),
         "orbgpu_set_batch_slices": (i32, [vp, i32]),
         "orbgpu_wait_event": (i32, [vp, vp]),

@@ -224,6 +224,12 @@ int ensure_slice(orbgpu_ctx *ctx, int s) {
 
 // drains and destroys every side stream and its events (they come back on demand)
 void release_side_streams(orbgpu_ctx *ctx) {
+  if (ctx->head_stream) {
+    (void)hipStreamSynchronize(ctx->head_stream);
+    (void)hipStreamDestroy(ctx->head_stream);
+    ctx->head_stream = nullptr;
+  }
+  ctx->head_ok_valid = false;  // (the context's stream is drained by every caller of this function)
   for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
     hipStream_t *st[3] = {&ctx->slice_stream[k], &ctx->slice_blur[k], &ctx->slice_l0[k]};
     for (hipStream_t *q : st)
@@ -273,6 +279,8 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   level_budget(ctx->params.scale_factor, L, feature_count, budget);
   // the device error flag is sticky: it is only cleared by finish_pipeline(), so queued calls cannot hide an error
   hipEvent_t *ev = ctx->ev[ctx->ev_head];
+  const bool head_ok_prev = ctx->head_ok_valid;  // (an early return below leaves it off)
+  ctx->head_ok_valid = false;
   int n_slices = ctx->n_slices > 0 ? ctx->n_slices : 1;
   n_slices = std::max(1, std::min(std::min(n_slices, (int)orbgpu_ctx::MAX_SLICES), n_frames));
   // an event between two kernels of a stream costs 6-7 us of stream time: by default only the FAST kernel is bracketed
@@ -286,6 +294,7 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   for (int s = 0; s < n_slices; s++) {
     const int f0 = (int)((long long)n_frames * s / n_slices), f1 = (int)((long long)n_frames * (s + 1) / n_slices);
     const FrameSlice fs{f0, f1 - f0, s == 0 ? ctx->stream : ctx->slice_stream[s]};
+    bool head_ok_here = false;
     const FrameSlice fb{f0, f1 - f0, ctx->no_overlap ? fs.stream : ctx->slice_blur[s]};
     hipEvent_t *sev = ctx->slice_ev[s];
     const bool timed = s == 0 && stage_timing;       // the stage timers follow slice 0
@@ -295,33 +304,53 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     // (level 0 needs no pyramid at all); the launch on the critical path covers the levels from E on
     const int E = ctx->early_l0 ? std::min(ctx->early_levels, L - 1) : 0;
     const FrameSlice fl{f0, f1 - f0, ctx->no_overlap ? fs.stream : ctx->slice_l0[s]};
+    // orbgpu_set_input_ready: the head (pyramid + FAST) of this call on a stream that does not wait for the context's
+    // stream -- the previous batch's descriptor and link kernels are gathers that wait on memory, the head is vector-ALU
+    // work -- but for the caller's input event and for the event the previous call recorded where it had read its
+    // pyramid, cells and candidates for the last time (behind orientation and blur).  Everything from the quadtree on
+    // stays on the context's stream, behind the head's end.
+    const bool patch = patch_mode(ctx, feature_count);
+    const bool piped = ctx->call_piped && head_ok_prev && n_slices == 1 && !capture && !stage_timing &&
+                       !ctx->no_overlap && !patch;
+    if (piped) {
+      if (!ctx->head_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->head_stream, hipStreamNonBlocking));
+      if (!ctx->ev_head_done) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_head_done, hipEventDisableTiming));
+      if (ctx->input_event) HIP_TRY(hipStreamWaitEvent(ctx->head_stream, ctx->input_event, 0));
+      HIP_TRY(hipStreamWaitEvent(ctx->head_stream, ctx->ev_head_ok, 0));
+    }
+    const FrameSlice fh{f0, f1 - f0, piped ? ctx->head_stream : fs.stream};
     if (E > 0) {
-      HIP_TRY(hipEventRecord(sev[3], fs.stream));  // after everything already on the stream (the caller's images included)
+      HIP_TRY(hipEventRecord(sev[3], fh.stream));  // after everything already on the stream (the caller's images included)
       HIP_TRY(hipStreamWaitEvent(fl.stream, sev[3], 0));
       if (timed) HIP_TRY(hipEventRecord(ev[10], fl.stream));
       launch_fast_cells(ctx, fl, nullptr, 0, 1, true);
       if (timed) HIP_TRY(hipEventRecord(ev[11], fl.stream));
     }
     for (int l = 1; l < L; l++) {
-      launch_pyramid_level(ctx, fs, l);
+      launch_pyramid_level(ctx, fh, l);
       if (l < E) {
-        HIP_TRY(hipEventRecord(sev[4 + l], fs.stream));
+        HIP_TRY(hipEventRecord(sev[4 + l], fh.stream));
         HIP_TRY(hipStreamWaitEvent(fl.stream, sev[4 + l], 0));
         launch_fast_cells(ctx, fl, nullptr, l, l + 1, true);
       }
     }
     if (E > 0) HIP_TRY(hipEventRecord(sev[4], fl.stream));
-    if (timed_fast) HIP_TRY(hipEventRecord(ev[1], fs.stream));
-    launch_fast_cells(ctx, fs, nullptr, E, L, false);
-    if (timed_fast) HIP_TRY(hipEventRecord(ev[2], fs.stream));
-    if (E > 0) HIP_TRY(hipStreamWaitEvent(fs.stream, sev[4], 0));  // the quadtree needs every level's cells
+    if (timed_fast) HIP_TRY(hipEventRecord(ev[1], fh.stream));
+    launch_fast_cells(ctx, fh, nullptr, E, L, false);
+    if (timed_fast) HIP_TRY(hipEventRecord(ev[2], fh.stream));
+    if (E > 0) HIP_TRY(hipStreamWaitEvent(fh.stream, sev[4], 0));  // the quadtree needs every level's cells
+    if (piped) {  // join: the context's stream continues behind the head
+      HIP_TRY(hipEventRecord(ctx->ev_head_done, fh.stream));
+      HIP_TRY(hipStreamWaitEvent(fs.stream, ctx->ev_head_done, 0));
+    }
     // the blur's fork point: the FAST kernel's end event when it has just been recorded (one event between two kernels
     // of the critical path instead of two)
     // patch mode (large images, few keypoints per pixel): no full-frame blur at all -- one kernel behind the quadtree takes
     // the orientation, blurs the keypoint's own 43 x 43 patch and runs the tests (k_patch_describe)
-    const bool patch = patch_mode(ctx, feature_count);
     ctx->last_patch_mode = patch;
-    hipEvent_t fork_ev = timed_fast ? ev[2] : sev[0];
+    // (a piped head may end before the previous call's descriptor kernel has read the blurred slab: the blur then forks
+    //  from the context's stream, behind the join, not from the FAST kernel's end event)
+    hipEvent_t fork_ev = timed_fast && !piped ? ev[2] : sev[0];
     if (fork_ev == sev[0] && !patch) HIP_TRY(hipEventRecord(sev[0], fs.stream));
     // the blur needs only the pyramid; it runs on its own stream beside the quadtree kernel, which is a chain of short
     // dependent rounds in levels x frames workgroups and leaves most of the chip idle
@@ -356,6 +385,11 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
       HIP_TRY(hipEventRecord(sev[1], fb.stream));
       HIP_TRY(hipStreamWaitEvent(fs.stream, sev[1], 0));
       if (timed) HIP_TRY(hipEventRecord(ev[5], fs.stream));
+      if (s == n_slices - 1 && n_slices == 1 && !capture) head_ok_here = true;
+      if (head_ok_here) {
+        if (!ctx->ev_head_ok) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_head_ok, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ctx->ev_head_ok, fs.stream));  // pyramid, cells and candidates have been read for the last time
+      }
       launch_describe(ctx, fs, d_kp, d_desc, capacity, d_n_out);
     }
     if (timed) HIP_TRY(hipEventRecord(ev[6], fs.stream));
@@ -365,6 +399,8 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     }
   }
   if (stage_timing) HIP_TRY(hipEventRecord(ev[9], ctx->stream));  // every slice has finished
+  // the next call's head may start behind ev_head_ok only if this call recorded it (one slice, full-frame blur, no capture)
+  ctx->head_ok_valid = n_slices == 1 && !capture && !ctx->last_patch_mode && ctx->ev_head_ok != nullptr;
   HIP_TRY(hipGetLastError());
   ctx->last_frames = n_frames;
   ctx->last_feature_count = feature_count;
@@ -539,6 +575,7 @@ int extract_one_frame_graph(orbgpu_ctx *ctx, const uint8_t *img, int stride, int
     HIP_TRY(e3);
     ctx->graph_one_features = feature_count;
   }
+  ctx->head_ok_valid = false;  // (the graph's kernels use the working buffers behind no event of the eager path)
   HIP_TRY(hipGraphLaunch(ctx->graph_one, ctx->stream));
   int rc = finish_pipeline(ctx);
   if (rc) return rc;
@@ -790,6 +827,8 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
     for (auto &ev : set)
       if (ev) (void)hipEventDestroy(ev);
   release_side_streams(ctx);
+  if (ctx->ev_head_ok) (void)hipEventDestroy(ctx->ev_head_ok);
+  if (ctx->ev_head_done) (void)hipEventDestroy(ctx->ev_head_done);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -890,13 +929,27 @@ int orbgpu_extract_batch_device(orbgpu_ctx *ctx, const uint8_t *d_imgs, int64_t 
   const LevelGeom &L0 = ctx->geom.lv[0];
   const bool in_place = stride == L0.pitch && frame_stride >= (int64_t)L0.pitch * L0.h &&
                         ((reinterpret_cast<uintptr_t>(d_imgs) | (uintptr_t)frame_stride) & 15) == 0 && !ctx->no_zero_copy;
+  // the caller's input event (orbgpu_set_input_ready): the context's stream waits for it whatever else happens -- a head
+  // on its own stream waits for it by itself
+  if (ctx->inputs_ready && ctx->input_event) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->input_event, 0));
   if (in_place) {
     ctx->lvl0 = Level0Src{d_imgs, (long long)frame_stride};
   } else {
     ctx->lvl0 = Level0Src{nullptr, 0};
     launch_import_images(ctx, d_imgs, frame_stride, stride, n_frames);
   }
-  return run_pipeline(ctx, n_frames, feature_count, d_kp, d_desc, capacity, d_n_out);
+  ctx->call_piped = ctx->inputs_ready && in_place;  // (an import copy runs on the context's stream)
+  const int rc = run_pipeline(ctx, n_frames, feature_count, d_kp, d_desc, capacity, d_n_out);
+  ctx->call_piped = false;
+  return rc;
+}
+
+int orbgpu_set_input_ready(orbgpu_ctx *ctx, int32_t ready, void *event) {
+  if (!ctx) return ORBGPU_E_INVALID;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  ctx->inputs_ready = ready != 0;
+  ctx->input_event = ready ? static_cast<hipEvent_t>(event) : nullptr;
+  return ORBGPU_OK;
 }
 
 int orbgpu_extract_batch(orbgpu_ctx *ctx, const uint8_t *const *imgs, int32_t n_frames, int32_t stride,

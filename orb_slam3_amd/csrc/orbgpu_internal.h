@@ -183,6 +183,15 @@ struct orbgpu_ctx {
   // one frame per host call (orbgpu_extract): the whole call as one captured graph, results in mapped host memory
   int patch_blur_forced = -1;          // ORBGPU_PATCH_BLUR: -1 by size (patch_mode), 0 never, 1 always
   bool last_patch_mode = false;        // the last extract call blurred per keypoint (k_patch_describe): d_blur was not written
+  // orbgpu_set_input_ready: the head of an orbgpu_extract_batch_device call (pyramid + FAST) on a stream of its own that
+  // waits for the caller's input event and for the previous call's last reader of the pyramid, not for the context's stream
+  bool inputs_ready = false;
+  hipEvent_t input_event = nullptr;    // the caller's (not owned); nullptr: the images are complete when the call is made
+  bool call_piped = false;             // this call qualifies (set by the entry point, read by run_pipeline)
+  hipStream_t head_stream = nullptr;
+  hipEvent_t ev_head_ok = nullptr;     // recorded on the context's stream where a call has read its pyramid for the last time
+  hipEvent_t ev_head_done = nullptr;   // this call's head is complete
+  bool head_ok_valid = false;          // ev_head_ok covers everything enqueued that touches the working buffers
   bool graph_single_frame = true;      // ORBGPU_NO_GRAPH=1: eager launches instead
   hipGraphExec_t graph_one = nullptr;  // upload + pipeline of one frame for graph_one_features keypoints
   int graph_one_features = 0;

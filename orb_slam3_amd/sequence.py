@@ -139,9 +139,13 @@ class SequenceRunner:
     batch size to walk in; source: a frame source (above).  ring: device image buffers in flight."""
 
     def __init__(self, extractor, source, feature_count, keyframe_every=10, window=100, threshold=50, ratio=0.9,
-                 check_orientation=True, ring=4, copy_streams=1):
+                 check_orientation=True, ring=4, copy_streams=1, input_ready=False):
         # one extractor, or a list of two of the same configuration: batches alternate between them
         self.fes = list(extractor) if isinstance(extractor, (list, tuple)) else [extractor]
+        # input_ready: hand the upload event to the library as the batch's input event instead of making its stream wait
+        # (orbgpu_set_input_ready: the call's head beside the previous batch's tail); pays when the extraction is the
+        # bound, costs upload rate when PCIe is (one more stream on the process's 4 hardware queues)
+        self.input_ready = bool(input_ready)
         self.fe, self.src = self.fes[0], source
         extractor = self.fe
         self.lib = _lib.load()
@@ -257,7 +261,12 @@ class SequenceRunner:
             if k + ahead < len(batches):
                 nb = batches[k + ahead]
                 bytes_up += self._upload(k + ahead, nb[0], nb[1] - nb[0])
-            self._check(lib.orbgpu_wait_event(h, self.ev_up[r].cuda_event), h)
+            # the batch's images are complete when its upload event fires: the library may start the call's pyramid and
+            # FAST kernels then, beside the previous batch's descriptor and link kernels (orbgpu_set_input_ready)
+            if self.input_ready:
+                self._check(lib.orbgpu_set_input_ready(h, 1, self.ev_up[r].cuda_event), h)
+            else:
+                self._check(lib.orbgpu_wait_event(h, self.ev_up[r].cuda_event), h)
             self._check(lib.orbgpu_extract_batch_device(h, self.batch_in[r].data_ptr(), self.H * self.W, self.W, c, nf,
                                                         S.d_kp[1].data_ptr(), S.d_desc[1].data_ptr(), cap,
                                                         S.d_n[1:].data_ptr()), h)
@@ -314,6 +323,8 @@ class SequenceRunner:
         t_enq = time.perf_counter() - t0
         for S in self.sets:
             self._check(lib.orbgpu_synchronize(S.h), S.h)      # also surfaces device-side capacity errors
+            if self.input_ready:
+                self._check(lib.orbgpu_set_input_ready(S.h, 0, None), S.h)
         for st in self.copy_streams:
             st.synchronize()
         t_all = time.perf_counter() - t0

@@ -393,3 +393,87 @@ def test_schedules_give_identical_results(monkeypatch, switch):
     assert ref[2].min() > 50
     for a, b in zip(ref, alt):
         assert np.array_equal(a, b)
+
+
+def test_input_ready_gives_identical_results():
+    """orbgpu_set_input_ready: the head of a call (pyramid + FAST) runs beside the previous call's descriptor and link
+    kernels.  Two different batches alternating through one context (a head that started too early, or a blur that
+    overwrote the slab the previous descriptors still read, would mix them up), with the link call in between, first with
+    the images complete at call time, then with an input event recorded behind a copy on another stream: every call's
+    outputs equal the plain-order ones"""
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    w, h, nf, b = 640, 480, 600, 24
+    seq = synth.sequence(555, 2 * b, h, w)
+    dev = torch.device("cuda", 0)
+    imgs = [torch.from_numpy(np.ascontiguousarray(seq[i * b:(i + 1) * b])).to(dev) for i in range(2)]
+    fe = ORBFeatureExtractor(w, h, 1.2, 8, 20, 7, max_batch=b, max_features=nf)
+    cap = fe.geometry(nf).keypoint_capacity
+    hd = fe.handle
+    to = torch.arange(1, b, dtype=torch.int32, device=dev)
+    frm = torch.arange(0, b - 1, dtype=torch.int32, device=dev)
+
+    def outputs(n):
+        return [(torch.zeros((b, cap, 32), dtype=torch.uint8, device=dev), torch.zeros((b, cap, 32), dtype=torch.uint8, device=dev),
+                 torch.zeros(b, dtype=torch.int32, device=dev), torch.full((b - 1, cap), -7, dtype=torch.int32, device=dev),
+                 torch.zeros((b - 1, cap), dtype=torch.int32, device=dev), torch.zeros(b - 1, dtype=torch.int32, device=dev))
+                for _ in range(n)]
+
+    def call(img, o):
+        kp, desc, n, mi, md, mc = o
+        _lib.check(lib.orbgpu_extract_batch_device(hd, img.data_ptr(), w * h, w, b, nf, kp.data_ptr(), desc.data_ptr(), cap, n.data_ptr()), hd)
+        _lib.check(lib.orbgpu_match_frames_device(hd, kp.data_ptr(), desc.data_ptr(), n.data_ptr(), cap, to.data_ptr(), frm.data_ptr(),
+                                                  b - 1, 100, 50, 0.9, 1, mi.data_ptr(), md.data_ptr(), mc.data_ptr()), hd)
+
+    n_calls = 6
+    ref = outputs(n_calls)
+    torch.cuda.synchronize()
+    for i in range(n_calls):
+        call(imgs[i & 1], ref[i])
+    _lib.check(lib.orbgpu_synchronize(hd), hd)
+
+    def same(a, b_):
+        n = a[2].cpu().numpy()
+        if not (torch.equal(a[2], b_[2]) and torch.equal(a[5], b_[5]) and torch.equal(a[3], b_[3])):
+            return False
+        ad, bd, ak, bk = a[1].cpu().numpy(), b_[1].cpu().numpy(), a[0].cpu().numpy(), b_[0].cpu().numpy()
+        return all(np.array_equal(ad[f, :n[f]], bd[f, :n[f]]) and np.array_equal(ak[f, :n[f]], bk[f, :n[f]]) for f in range(b))
+
+    # (1) images complete when the call is made
+    got = outputs(n_calls)
+    torch.cuda.synchronize()
+    _lib.check(lib.orbgpu_set_input_ready(hd, 1, None), hd)
+    for i in range(n_calls):
+        call(imgs[i & 1], got[i])
+    _lib.check(lib.orbgpu_synchronize(hd), hd)
+    for i in range(n_calls):
+        assert same(ref[i], got[i]), f"call {i}"
+    # (2) images written by a copy on another stream, the call made at once with the copy's event
+    got = outputs(n_calls)
+    ring = [torch.zeros_like(imgs[0]) for _ in range(2)]
+    side = torch.cuda.Stream(dev)
+    evs = [torch.cuda.Event() for _ in range(n_calls)]
+    free = [torch.cuda.Event() for _ in range(n_calls)]
+    torch.cuda.synchronize()
+    for i in range(n_calls):
+        with torch.cuda.stream(side):
+            if i >= 2:
+                side.wait_event(free[i - 2])   # the call that read this ring slot has finished
+            ring[i & 1].copy_(imgs[i & 1], non_blocking=True)
+            evs[i].record(side)
+        _lib.check(lib.orbgpu_set_input_ready(hd, 1, evs[i].cuda_event), hd)
+        call(ring[i & 1], got[i])
+        free[i].record(torch.cuda.ExternalStream(int(lib.orbgpu_stream(hd)), device=dev))
+    _lib.check(lib.orbgpu_synchronize(hd), hd)
+    _lib.check(lib.orbgpu_set_input_ready(hd, 0, None), hd)
+    for i in range(n_calls):
+        assert same(ref[i], got[i]), f"call {i} (event)"
+    # plain order again on the same context
+    got = outputs(2)
+    for i in range(2):
+        call(imgs[i & 1], got[i])
+    _lib.check(lib.orbgpu_synchronize(hd), hd)
+    assert same(ref[0], got[0]) and same(ref[1], got[1])
+    fe.close()
