@@ -221,6 +221,12 @@ def test_two_contexts_alternating(runner):
             assert same, f"keyframe {q}"
     for b in (B, 2 * B, 3 * B):  # the links into the first frame of a batch come from the other context's outputs
         assert one.n_links[b] > 50
+    # the input-ready hint (a call's head beside the previous call's tail), one context and two
+    for fes in (runner.fe, [runner.fe, fe_b]):
+        got = SequenceRunner(fes, pool, NF, keyframe_every=EVERY, input_ready=True).run(n, keep_links=True)
+        assert np.array_equal(one.n_keypoints, got.n_keypoints) and np.array_equal(one.n_links, got.n_links)
+        assert np.array_equal(one.links, got.links)
+        assert bool((one.kf_n == got.kf_n).all())
     # 2 ranks, two contexts each: the block + halo arithmetic is untouched
     parts = [two_runner.run(n, rank=r, world=2, keep_links=True) for r in range(2)]
     assert np.array_equal(np.concatenate([p.n_links for p in parts]), one.n_links)
