@@ -61,6 +61,13 @@ for c in (a, b):
 for rep in range(3):
     t1 = run([a], K)
     t2 = run([a, b], K)
+    st1 = None
+    a.fe.stage_times()
+    t1 = run([a], K)
+    st1 = a.fe.stage_times()["fast_score"]
+    t2 = run([a, b], K)
+    st2 = a.fe.stage_times()["fast_score"]
+    print(f"   FAST launch of the levels >= 1: {st1:.4f} ms alone, {st2:.4f} ms with two contexts alternating")
     print(f"one context {t1:.4f} ms/step ({B / t1:.1f} k frames/s)   two contexts alternating {t2:.4f} ms/step ({B / t2:.1f} k frames/s)", flush=True)
 ref_n = a.n.cpu().numpy().copy()
 assert np.array_equal(ref_n, b.n.cpu().numpy()) and torch.equal(a.desc, b.desc) and torch.equal(a.mi, b.mi)
