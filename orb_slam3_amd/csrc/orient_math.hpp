@@ -1,0 +1,122 @@
+// Intensity-centroid orientation (IC_Angle, src/features/orb_feature_extractor.cpp:177-202; cv::fastAtan2 :201): the
+// weight table, the arc tangent and the per-wave evaluation, shared by k_orient / k_patch_describe (k_describe.hip) and by
+// the quadtree kernel's fused tail (k_quadtree.hip).  Each translation unit keeps its own __constant__ copy of the table
+// (make_orient_tab) and stages it in LDS.  gfx950 only.
+#pragma once
+
+#include <cfloat>
+
+#include "orbgpu_internal.h"
+
+namespace orient {
+
+// umax_, orb_feature_extractor.cpp:678-679
+constexpr int UMAX[ORB_HALF_PATCH + 1] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+// Orientation weights.  The 31 rows of the disc are read as 9 aligned dwords starting at xo = (cx-15) & ~3; with
+// sh = (cx-15) - xo, byte b of dword c of row r is the pixel u = 4c + b - 15 - sh, v = r - 15.  Per (sh, r, c):
+//   .x = bytes (u + 15) inside the disc, 0 outside   -> v_dot4_u32_u8 gives sum (u+15) I
+//   .y = bytes 1 inside the disc, 0 outside           -> v_dot4_u32_u8 gives sum I
+// so m10 = sum (u+15) I - 15 sum I and m01 = sum over rows of v * (row's sum I).
+constexpr int ODW = 9;                   // aligned dwords covering a 31-byte orientation row
+constexpr int OT_STRIDE = 64 * 5;        // entries per shift (31*9 = 279 used; lane + 63k indexing stays inside)
+struct OrientTab { uint2 e[4 * OT_STRIDE]; };
+constexpr OrientTab make_orient_tab() {
+  OrientTab t{};
+  for (int sh = 0; sh < 4; sh++)
+    for (int r = 0; r < ORB_PATCH; r++)
+      for (int c = 0; c < ODW; c++) {
+        const int v = r - ORB_HALF_PATCH;
+        const int um = UMAX[v < 0 ? -v : v];
+        unsigned w = 0, m = 0;
+        for (int b = 0; b < 4; b++) {
+          const int u = 4 * c + b - ORB_HALF_PATCH - sh;
+          if (u >= -um && u <= um) {
+            w |= (unsigned)(u + ORB_HALF_PATCH) << (8 * b);
+            m |= 1u << (8 * b);
+          }
+        }
+        t.e[sh * OT_STRIDE + r * ODW + c] = uint2{w, m};
+      }
+  return t;
+}
+
+// cv::fastAtan2 scalar path: float32, no contraction, correctly rounded divide.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+  const float p1 = 0.9997878412794807f * scale;
+  const float p3 = -0.3258083974640975f * scale;
+  const float p5 = 0.1555786518463281f * scale;
+  const float p7 = -0.04432655554792128f * scale;
+  const float eps = (float)DBL_EPSILON;
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  } else {
+    c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fsub_rn(90.f,
+                  __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+  }
+  if (x < 0) a = __fsub_rn(180.f, a);
+  if (y < 0) a = __fsub_rn(360.f, a);
+  return a;
+}
+
+
+// IC_Angle of NK keypoints side by side by ONE wave (NK times the loads in flight), in two steps so that a caller can
+// put a barrier (the table's staging) between them.  lvl[h] / pitch[h]: the unblurred level of keypoint h; (cx, cy) and
+// valid are wave-uniform.  31 rows x 9 aligned dwords, 7 rows = 63 lanes per step.
+template <int NK>
+__device__ __forceinline__ void orient_load(const uint8_t *const (&lvl)[NK], const int (&pitch)[NK], const int (&cx)[NK],
+                                            const int (&cy)[NK], const bool (&valid)[NK], int lane, unsigned (&ov)[NK][5]) {
+  const int osub = lane / ODW, oc4 = 4 * (lane - osub * ODW);
+#pragma unroll
+  for (int h = 0; h < NK; h++) {
+    const int xo = (cx[h] - ORB_HALF_PATCH) & ~3;
+    const uint8_t *osrc = lvl[h] + (size_t)(cy[h] - ORB_HALF_PATCH) * pitch[h] + xo;
+    const unsigned ooff = (unsigned)(osub * pitch[h] + oc4);
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      ov[h][k] = 0;
+      if (valid[h] && lane < 63 && 7 * k + osub < ORB_PATCH)
+        ov[h][k] = *reinterpret_cast<const unsigned *>(osrc + (ooff + (unsigned)(7 * k * pitch[h])));
+    }
+  }
+}
+
+// the angles from the loaded rows (every lane returns them); s_tab: the weight table in LDS
+template <int NK>
+__device__ __forceinline__ void orient_angles(const unsigned (&ov)[NK][5], const int (&cx)[NK], const bool (&valid)[NK],
+                                              const uint2 *s_tab, int lane, float (&ang)[NK]) {
+  const int osub = lane / ODW;
+#pragma unroll
+  for (int h = 0; h < NK; h++) {
+    ang[h] = 0.f;
+    if (!valid[h]) continue;
+    const int osh = (cx[h] - ORB_HALF_PATCH) & 3;
+    unsigned a10 = 0, si = 0;
+    int m01 = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      // rows beyond the disc and lane 63 read weight 0 / pixel 0
+      const uint2 ow = s_tab[osh * OT_STRIDE + 63 * k + min(lane, 62)];
+      const unsigned rs = __builtin_amdgcn_udot4(ov[h][k], ow.y, 0u, false);
+      a10 = __builtin_amdgcn_udot4(ov[h][k], ow.x, a10, false);
+      si += rs;
+      m01 += (7 * k + osub - ORB_HALF_PATCH) * (int)rs;
+    }
+    int m10 = (int)a10 - ORB_HALF_PATCH * (int)si;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      m10 += __shfl_xor(m10, off);
+      m01 += __shfl_xor(m01, off);
+    }
+    ang[h] = fast_atan2_deg((float)m01, (float)m10);
+  }
+}
+
+}  // namespace orient
