@@ -29,33 +29,70 @@ __device__ __forceinline__ int vmax3(int a, int b, int c) {
   return r;
 }
 
-// the same score for a pixel that already passed the opposite-pair test (no early-out): 16 sub + 64 min3/max3 for
-// the 9-windows of both polarities + 16 for the two reductions
-__device__ __forceinline__ int fast_score16_full(int v, const int (&r)[16], int min_thr) {
-  int d[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) d[k] = v - r[k];
-  int mn3[16], mx3[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mn3[k] = vmin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-    mx3[k] = vmax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+// Packed 3-input minimum / maximum on the two 16-bit halves of a register (gfx950: v_pk_minimum3_f16 /
+// v_pk_maximum3_f16).  The operands are pixel values 0..255 sitting in the halves as integers, i.e. read as f16 they are
+// denormals b * 2^-24, which order exactly like the integers (f16 denormals are not flushed: the kernel runs with the
+// default mode, denormals on for f16) and come out bit for bit.  SW: bit i set <=> operand i enters with its halves
+// exchanged (op_sel modifiers, no instruction).
+#define ORBGPU_PK3(NAME, OP)                                                                                          \
+  template <int SW>                                                                                                   \
+  __device__ __forceinline__ unsigned NAME(unsigned a, unsigned b, unsigned c) {                                      \
+    unsigned r;                                                                                                       \
+    static_assert(SW == 0 || SW == 2 || SW == 4 || SW == 6, "operand 0 is never exchanged");                          \
+    if constexpr (SW == 0) asm(OP " %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));                              \
+    else if constexpr (SW == 2) asm(OP " %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c)); \
+    else if constexpr (SW == 4) asm(OP " %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c)); \
+    else asm(OP " %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));               \
+    return r;                                                                                                         \
   }
-  int mn9[16], mx9[16];
+ORBGPU_PK3(pk_min3, "v_pk_minimum3_f16")
+ORBGPU_PK3(pk_max3, "v_pk_maximum3_f16")
+#undef ORBGPU_PK3
+
+// The score of a pixel that already passed the quick test (no early-out).  With d_k = v - ring_k,
+//   M_dark = max over arcs of min over the arc of d = v - min over arcs of (max over the arc of ring),
+//   M_bright = (max over arcs of (min over the arc of ring)) - v,
+// so the window network runs on the ring pixels themselves, for both polarities, two ring positions per instruction:
+// P[k] = ring_k | ring_{k+8} << 16 (k = 0..7).  The 3-windows of positions k and k + 8 are one packed operation on
+// P[k], P[k+1], P[k+2], where an index beyond 7 is the register of index - 8 with its halves exchanged; the 9-windows
+// likewise from the 3-windows at k, k + 3, k + 6.  8 + 8 operations per polarity, 5 for the reduction over the 16 arcs.
+__device__ __forceinline__ int fast_score16_full(int v, const unsigned (&P)[8], int min_thr) {
+  unsigned mn3[8], mx3[8];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mn9[k] = vmin3(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
-    mx9[k] = vmax3(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
+  for (int k = 0; k < 6; k++) {
+    mn3[k] = pk_min3<0>(P[k], P[k + 1], P[k + 2]);
+    mx3[k] = pk_max3<0>(P[k], P[k + 1], P[k + 2]);
   }
-  int m_dark = vmax3(mn9[0], mn9[1], mn9[2]), m_brightneg = vmin3(mx9[0], mx9[1], mx9[2]);
+  mn3[6] = pk_min3<4>(P[6], P[7], P[0]);
+  mx3[6] = pk_max3<4>(P[6], P[7], P[0]);
+  mn3[7] = pk_min3<6>(P[7], P[0], P[1]);
+  mx3[7] = pk_max3<6>(P[7], P[0], P[1]);
+  unsigned mn9[8], mx9[8];
 #pragma unroll
-  for (int k = 3; k < 15; k += 2) {
-    m_dark = vmax3(m_dark, mn9[k], mn9[k + 1]);
-    m_brightneg = vmin3(m_brightneg, mx9[k], mx9[k + 1]);
+  for (int k = 0; k < 2; k++) {
+    mn9[k] = pk_min3<0>(mn3[k], mn3[k + 3], mn3[k + 6]);
+    mx9[k] = pk_max3<0>(mx3[k], mx3[k + 3], mx3[k + 6]);
   }
-  m_dark = max(m_dark, mn9[15]);
-  m_brightneg = min(m_brightneg, mx9[15]);
-  int s = max(m_dark, -m_brightneg) - 1;
+#pragma unroll
+  for (int k = 2; k < 5; k++) {
+    mn9[k] = pk_min3<4>(mn3[k], mn3[k + 3], mn3[k - 2]);
+    mx9[k] = pk_max3<4>(mx3[k], mx3[k + 3], mx3[k - 2]);
+  }
+#pragma unroll
+  for (int k = 5; k < 8; k++) {
+    mn9[k] = pk_min3<6>(mn3[k], mn3[k - 5], mn3[k - 2]);
+    mx9[k] = pk_max3<6>(mx3[k], mx3[k - 5], mx3[k - 2]);
+  }
+  unsigned lo = pk_min3<0>(mx9[0], mx9[1], mx9[2]), hi = pk_max3<0>(mn9[0], mn9[1], mn9[2]);
+  lo = pk_min3<0>(lo, mx9[3], mx9[4]);
+  hi = pk_max3<0>(hi, mn9[3], mn9[4]);
+  lo = pk_min3<0>(lo, mx9[5], mx9[6]);
+  hi = pk_max3<0>(hi, mn9[5], mn9[6]);
+  lo = pk_min3<0>(lo, mx9[7], mx9[7]);
+  hi = pk_max3<0>(hi, mn9[7], mn9[7]);
+  lo = pk_min3<2>(lo, lo, lo);  // low half: over both halves
+  hi = pk_max3<2>(hi, hi, hi);
+  const int s = max(v - (int)(lo & 0xffffu), (int)(hi & 0xffffu) - v) - 1;
   return s >= min_thr ? s : 0;
 }
 
@@ -82,7 +119,7 @@ __device__ __forceinline__ u16x2 pair_bytes(const unsigned (&w)[3]) {
 // more: 6.7 % instead of 6.2 % of the pixels at t = 20).  The exact score decides afterwards.  Four opposite pairs (the
 // even ring positions); only full-rate operations (shift, and, or, add, sub) but for six v_alignbyte_b32.
 // tw -> dword left of the quad in tile row y - 3.  Returns bit 7 of byte p set <=> pixel p may be a corner at `ka`'s
-// threshold (BOTH: at ka's and not at kb's).
+// threshold.
 __device__ __forceinline__ unsigned quant6(unsigned x) {
   unsigned m = 0x3f3f3f3fu;
   asm volatile("" : "+s"(m));
@@ -93,8 +130,8 @@ __device__ __forceinline__ unsigned quant6(unsigned x) {
 __device__ __forceinline__ unsigned or_and(unsigned x, unsigned y, unsigned z) { return (x | y) & z; }
 
 // RAW: the tile holds the pixels themselves (quantised here); else the tile quantised at staging time
-template <bool RAW, bool BOTH>
-__device__ __forceinline__ unsigned quick_quad(const unsigned *tw, unsigned ka, unsigned kb) {
+template <bool RAW>
+__device__ __forceinline__ unsigned quick_quad(const unsigned *tw, unsigned ka) {
   constexpr int TP = 36;  // FC_TP
   auto qz = [](unsigned x) { return RAW ? quant6(x) : x; };
   const unsigned r0 = qz(tw[6 * TP + 1]), r8 = qz(tw[1]);                         // (0, 3), (0, -3)
@@ -105,14 +142,10 @@ __device__ __forceinline__ unsigned quick_quad(const unsigned *tw, unsigned ka, 
   const unsigned ca = tw[3 * TP], cb = tw[3 * TP + 1], cc = tw[3 * TP + 2];       // row y: (3, 0), (-3, 0), centre
   const unsigned r4 = qz(__builtin_amdgcn_alignbyte(cc, cb, 3)), r12 = qz(__builtin_amdgcn_alignbyte(cb, ca, 1));
   const unsigned v = qz(cb);
-  auto test = [&](unsigned k) {
-    const unsigned va = v + k, vb = k - v;
-    const unsigned dark = or_and(va - r6, va - r14, or_and(va - r4, va - r12, or_and(va - r2, va - r10, (va - r0) | (va - r8))));
-    const unsigned bright = or_and(r6 + vb, r14 + vb, or_and(r4 + vb, r12 + vb, or_and(r2 + vb, r10 + vb, (r0 + vb) | (r8 + vb))));
-    return dark | bright;
-  };
-  if (BOTH) return test(ka) & ~test(kb);
-  return test(ka);
+  const unsigned va = v + ka, vb = ka - v;
+  const unsigned dark = or_and(va - r6, va - r14, or_and(va - r4, va - r12, or_and(va - r2, va - r10, (va - r0) | (va - r8))));
+  const unsigned bright = or_and(r6 + vb, r14 + vb, or_and(r4 + vb, r12 + vb, or_and(r2 + vb, r10 + vb, (r0 + vb) | (r8 + vb))));
+  return dark | bright;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -170,24 +203,19 @@ __host__ __device__ constexpr size_t fast_cells_lds_bytes(int rows) {
          + 16;
 }
 
-__device__ __forceinline__ int div_small(int q, int d, float inv_d) {
-  // q / d for 0 <= q < 2^20, 1 <= d: estimate + two-sided fix-up
-  int r = (int)((float)q * inv_d);
-  const int rem = q - r * d;
-  if (rem < 0) r--;
-  if (rem >= d) r++;
-  return r;
-}
-
 // inclusive prefix sum over the 64 lanes of a wave: four row_shr steps inside each 16-lane row, then the row totals
 // travel with row_bcast:15 / row_bcast:31 (lanes without a source add 0)
+// Written out: from update_dpp + add the compiler makes v_mov 0 / v_mov_dpp / v_add, three instructions a step; the add
+// takes the shifted operand itself (a lane without a source is not written and keeps its own value).  s_nop 1: the two
+// wait states between a vector write and a DPP read of the same register.
 __device__ __forceinline__ int wave_incl_scan(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+v"(v));
   return v;
 }
 
@@ -264,7 +292,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < (nrow + 2) * (FC_TP / 4); i += 256) reinterpret_cast<uint4 *>(stile)[i] = z4;
     if (tid < (nrow * FC_MAXK + 1) / 2) reinterpret_cast<uint4 *>(rmask)[tid] = z4;
-    if (tid < 2) q_count[tid] = 0;  // [0] packed queue counts, [1] bit j: cell j falls back to minThFAST
+    if (tid < 2) q_count[tid] = 0;  // [0] entries in the queue, [1] bit j: cell j falls back to minThFAST
     if (tid < FC_TPB) {  // a byte (0 / 1) per tile column beyond the left apron: a thread per pixel, 36 quads
       const int x = xs0 + tid;
       reinterpret_cast<uint8_t *>(colmask)[tid] = (x >= X0 && x <= X1) ? 1 : 0;
@@ -285,7 +313,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   FC_STOP(1);
 
   const int t_lo = g.fast_min, t_hi = g.fast_init;
-  const int qcap = lds_rows * FC_QPITCH;
   // quantised thresholds of the quick test (quick_quad) and their per-byte constants 128 - a
   const int a_lo = (t_lo + 1) >> 2, a_hi = (t_hi + 1) >> 2;
   const unsigned ka_lo = 0x80808080u - 0x01010101u * (unsigned)a_lo, ka_hi = 0x80808080u - 0x01010101u * (unsigned)a_hi;
@@ -294,16 +321,18 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   //      loop, the column mask is loaded once); the lanes beyond R * nw idle.  Survivors of up to 8 passes collect in one
   //      register, bit 8 * p + pass for pixel p of the lane's quad; 16 passes cover 64 rows at R >= 7 (nw <= 33).
   //      LO = false: the test at iniThFAST on the tile quantised at staging time.  LO = true (only when a cell of the
-  //      group falls back to minThFAST, and then only over the columns of such cells): pixels that pass at minThFAST and
-  //      not at iniThFAST, from the raw tile (the quantised one is the queue by then).  A pixel scoring below iniThFAST can
-  //      neither be kept nor suppress anything in a cell that keeps a corner at iniThFAST (NMS is a strict > against a
-  //      value >= iniThFAST), so the first round needs no more.
+  //      group falls back to minThFAST, and then only over the columns of such cells): the test at minThFAST, from the
+  //      raw tile (the quantised one is the queue by then).  A pixel scoring below iniThFAST can neither be kept nor
+  //      suppress anything in a cell that keeps a corner at iniThFAST (NMS is a strict > against a value >= iniThFAST),
+  //      so the first round needs no more.
   struct QuickLane { unsigned acc[2]; unsigned e0; int R; };
   auto quick_round = [&](int qa, int nw, auto lo_tag) -> QuickLane {
     constexpr bool LO = decltype(lo_tag)::value;
-    const float inv_nw = 1.0f / (float)nw;
-    const int R = __builtin_amdgcn_readfirstlane(div_small(256, nw, inv_nw));
-    const int r0 = div_small(tid, nw, inv_nw), cq = qa + tid - r0 * nw;
+    // tid / nw and 256 / nw by a 16-bit reciprocal: with M = floor(65536 / nw) + 1 or + 2 (the float estimate is within
+    // 0.02 of 65536 / nw) M * nw - 65536 <= 2 * nw <= 72, and n * M >> 16 == n / nw for every n * 72 < 65536
+    const unsigned M = __builtin_amdgcn_readfirstlane((unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)nw)) + 1u);
+    const int R = (int)((256u * M) >> 16);
+    const int r0 = (int)(((unsigned)tid * M) >> 16), cq = qa + tid - r0 * nw;
     const bool on = r0 < R;
     const unsigned cm = colmask[cq];
     const unsigned *tw = (LO ? tile : qtile) + r0 * FC_TP + cq;
@@ -319,7 +348,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
 #pragma unroll 1
       for (int k = 0; k < 8 && top < nrow; k++) {
         if (on && row < nrow) {
-          const unsigned hb = LO ? quick_quad<true, true>(tw, ka_lo, ka_hi) : quick_quad<false, false>(tw, ka_hi, 0u);
+          const unsigned hb = LO ? quick_quad<true>(tw, ka_lo) : quick_quad<false>(tw, ka_hi);
           acc |= ((hb >> 7) & cm) << k;
         }
         row += R;
@@ -335,41 +364,39 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   // the queue is free.  Entries are (row << 8 | tile column - 4).  The atomic is written out because the compiler wraps
   // an atomicAdd under `lane == 0` into a second reduction over the (one) active lane.
   const unsigned qc_addr = (unsigned)reinterpret_cast<size_t>(q_count);
-  auto push_block = [&](unsigned m, unsigned e0, int R, bool back) {
+  auto push_block = [&](unsigned m, unsigned e0, int R) {
     const int cnt = __popc(m);
     const int incl = wave_incl_scan(cnt);
     const int tot = __builtin_amdgcn_readlane(incl, 63);
     if (tot == 0) return;
     unsigned old = 0;
     if (lane == 0)
-      asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(qc_addr), "v"(back ? tot << 16 : tot) : "memory");
+      asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(qc_addr), "v"(tot) : "memory");
     old = __builtin_amdgcn_readfirstlane(old);
-    int pos = back ? qcap - 1 - ((int)(old >> 16) + incl - cnt) : (int)(old & 0xffff) + incl - cnt;
-    const int dir = back ? -1 : 1;
+    int pos = (int)old + incl - cnt;
     const unsigned rstep = (unsigned)R << 8;
     while (m) {
       const int bit = __ffs(m) - 1;
       m &= m - 1;
-      queue[pos] = (unsigned short)(e0 + (unsigned)(bit & 7) * rstep + ((unsigned)bit >> 3));
-      pos += dir;
+      queue[pos++] = (unsigned short)(e0 + (unsigned)(bit & 7) * rstep + ((unsigned)bit >> 3));
     }
   };
-  auto push_round = [&](const QuickLane &ql, bool back) {
-    push_block(ql.acc[0], ql.e0, ql.R, back);
-    if (8 * ql.R < nrow) push_block(ql.acc[1], ql.e0 + ((unsigned)(8 * ql.R) << 8), ql.R, back);
+  auto push_round = [&](const QuickLane &ql) {
+    push_block(ql.acc[0], ql.e0, ql.R);
+    if (8 * ql.R < nrow) push_block(ql.acc[1], ql.e0 + ((unsigned)(8 * ql.R) << 8), ql.R);
   };
   {
     const QuickLane ql = quick_round(0, ncg, std::false_type{});
     FC_STAMP(5);  // quick-test passes
     FC_STOP(2);
     __syncthreads();  // the queue takes the place of the quantised tile
-    push_round(ql, false);
+    push_round(ql);
   }
   FC_STAMP(6);  // push
   __syncthreads();
   FC_STAMP(7);
   FC_STOP(3);
-  const int n_hi = *q_count & 0xffff;
+  const int n_hi = *q_count;
   const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
   uint8_t *sb = reinterpret_cast<uint8_t *>(stile);
   const int bnd0 = X0 - xs0;  // tile column - 4 of the first pixel of cell j0
@@ -379,12 +406,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int ey = e >> 8, cx = e & 255;
     const uint8_t *c = tb + (ey + 3) * FC_TPB + cx + 4;
     constexpr int RP = FC_TPB;
-    int r[16];
-    r[0] = c[3 * RP];       r[1] = c[3 * RP + 1];   r[2] = c[2 * RP + 2];   r[3] = c[RP + 3];
-    r[4] = c[3];            r[5] = c[-RP + 3];      r[6] = c[-2 * RP + 2];  r[7] = c[-3 * RP + 1];
-    r[8] = c[-3 * RP];      r[9] = c[-3 * RP - 1];  r[10] = c[-2 * RP - 2]; r[11] = c[-RP - 3];
-    r[12] = c[-3];          r[13] = c[RP - 3];      r[14] = c[2 * RP - 2];  r[15] = c[3 * RP - 1];
-    const int sc = fast_score16_full((int)c[0], r, t_lo);
+    // ring positions k and k + 8 (opposite pixels) side by side in one register
+    unsigned P[8];
+    P[0] = c[3 * RP] | (unsigned)c[-3 * RP] << 16;          P[1] = c[3 * RP + 1] | (unsigned)c[-3 * RP - 1] << 16;
+    P[2] = c[2 * RP + 2] | (unsigned)c[-2 * RP - 2] << 16;  P[3] = c[RP + 3] | (unsigned)c[-RP - 3] << 16;
+    P[4] = c[3] | (unsigned)c[-3] << 16;                    P[5] = c[-RP + 3] | (unsigned)c[RP - 3] << 16;
+    P[6] = c[-2 * RP + 2] | (unsigned)c[2 * RP - 2] << 16;  P[7] = c[-3 * RP + 1] | (unsigned)c[3 * RP - 1] << 16;
+    const int sc = fast_score16_full((int)c[0], P, t_lo);
     if (sc) {
       sb[(ey + 1) * FC_TPB + cx + 4] = (uint8_t)sc;
       if (DUMP) score_dump[(size_t)frame * g.frame_bytes + L.off + (size_t)(Y0 + ey) * L.pitch + (xs0 + cx)] = (uint8_t)sc;
@@ -467,7 +495,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   const unsigned fallback = (unsigned)q_count[1];
   const unsigned score_mask = DUMP ? 0xfu : fallback;
   if (score_mask == 0) return;
-  // second quick-test round over the quad columns of the cells in score_mask: per-quad masks narrowed to those cells
+  // second quick-test round over the quad columns of the cells in score_mask: per-quad masks narrowed to those cells.
+  // The queue starts again from its front (its iniThFAST entries are done with: the cells they belong to have either
+  // been emitted or are tested again now -- what passes the quick test at iniThFAST passes it at minThFAST, and scoring
+  // a pixel twice writes the same value twice)
   const int j_a = __ffs(score_mask) - 1, j_b = min(31 - __clz(score_mask), (int)G.ncell - 1);
   const int qa_lo = (X0 + j_a * L.wcell - xs0) >> 2;
   const int nw_lo = ((min(X0 + (j_b + 1) * L.wcell - 1, X1) - xs0) >> 2) - qa_lo + 1;
@@ -476,15 +507,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int j = (rel >= L.wcell) + (rel >= 2 * L.wcell) + (rel >= 3 * L.wcell);
     reinterpret_cast<uint8_t *>(colmask)[tid] = (rel >= 0 && rel <= X1 - X0 && ((score_mask >> j) & 1u)) ? 1 : 0;
   }
+  if (tid == 0) q_count[0] = 0;
   __syncthreads();
-  push_round(quick_round(qa_lo, nw_lo, std::true_type{}), true);
+  push_round(quick_round(qa_lo, nw_lo, std::true_type{}));
   __syncthreads();
-  const int n_lo = *q_count >> 16;
-  for (int q = qcap - 1 - tid; q >= qcap - n_lo; q -= 256) score_entry(q);
+  const int n_lo = *q_count;
+  for (int q = tid; q < n_lo; q += 256) score_entry(q);
   if (fallback == 0) return;
   __syncthreads();
-  for (int q = tid; q < n_hi; q += 256) nms_entry(q, 1, fallback);
-  for (int q = qcap - 1 - tid; q >= qcap - n_lo; q -= 256) nms_entry(q, 1, fallback);
+  for (int q = tid; q < n_lo; q += 256) nms_entry(q, 1, fallback);
   __syncthreads();
   if (wave < G.ncell && ((fallback >> wave) & 1u)) {
     if (emit_cell(wave) == 0 && lane == 0) ce[wave] = CellEntry{(G.row * L.ncols + G.j0 + wave) * cell_slot, 0};

@@ -15,7 +15,8 @@ __device__ __forceinline__ bool xcd_item_frame(int items_per_frame, int n_frames
   const unsigned j = id >> 3;
   // j / items_per_frame from a float estimate and a two-sided fix-up: the quotient (a frame-group index) is far
   // below 2^22, so the estimate is off by at most one
-  int fq = (int)((float)j * (1.0f / (float)items_per_frame));
+  // (v_rcp_f32, 1 ulp, instead of the 12-instruction IEEE division: the fix-up below absorbs it)
+  int fq = (int)((float)j * __builtin_amdgcn_rcpf((float)items_per_frame));
   int it = (int)j - fq * items_per_frame;
   if (it < 0) { fq--; it += items_per_frame; }
   if (it >= items_per_frame) { fq++; it -= items_per_frame; }
