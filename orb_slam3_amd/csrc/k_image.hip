@@ -333,8 +333,14 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   const bool writes = j >= 1 && j <= nd;
   const u16x2 we0 = {18, 34}, we1 = {48, 56}, we2 = {48, 34}, we3 = {18, 0};   // even output row of a pair window
   const u16x2 wo0 = {0, 18}, wo1 = {34, 48}, wo2 = {56, 48}, wo3 = {34, 18};   // odd
-  const uint8_t *lsrc = src + ld_off;
-  uint8_t *ldst = dst + gx;
+  // Buffer addressing: the level is the (scalar) base, a lane carries a 32-bit byte offset, the row step k * pitch of a
+  // chunk's loads is a scalar offset -- no 64-bit address arithmetic per row.  Stores: a lane that writes nothing
+  // (strip halo, beyond the strip) keeps an offset beyond the level, and so do the rows below the image: the
+  // descriptor's range drops them, no compare and no branch per row.
+  const unsigned level_bytes = (unsigned)h * (unsigned)pitch;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, (int)level_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)level_bytes, 0x00020000);
+  unsigned ooff = writes ? (unsigned)gx + (unsigned)y0 * (unsigned)pitch : 0x80000000u;  // the next output row's dword
 
   // byte offset of staged row r (image row y0 - 3 + r, reflected)
   auto row_off = [&](int r) -> unsigned {
@@ -345,7 +351,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   };
   unsigned buf[2][8];  // the chunk being processed and the one in flight (the chunk loop is unrolled: no copies)
 #pragma unroll
-  for (int k = 0; k < 8; k++) buf[0][k] = *reinterpret_cast<const unsigned *>(lsrc + row_off(k));
+  for (int k = 0; k < 8; k++) buf[0][k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)ld_off + row_off(k), 0, 0);
+  const unsigned c128 = 128u;
   unsigned P[4][4];  // the last four row pairs, horizontally blurred: pixel p of (row 2m, row 2m + 1) in u16 halves
 #pragma unroll
   for (int a = 0; a < 4; a++)
@@ -359,12 +366,12 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
       const int yb = y0 - 3 + 8 * (c + 1);
       const bool inside = __builtin_amdgcn_readfirstlane(__all(yb >= 0 && yb + 7 < h));
       if (inside) {
-        const uint8_t *rp = lsrc + (unsigned)yb * (unsigned)pitch;
+        const unsigned voff = (unsigned)ld_off + (unsigned)yb * (unsigned)pitch;
 #pragma unroll
-        for (int k = 0; k < 8; k++) nxt[k] = *reinterpret_cast<const unsigned *>(rp + k * pitch);
+        for (int k = 0; k < 8; k++) nxt[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, k * pitch, 0);
       } else {
 #pragma unroll
-        for (int k = 0; k < 8; k++) nxt[k] = *reinterpret_cast<const unsigned *>(lsrc + row_off(8 * (c + 1) + k));
+        for (int k = 0; k < 8; k++) nxt[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)ld_off + row_off(8 * (c + 1) + k), 0, 0);
       }
     }
 #pragma unroll
@@ -375,10 +382,10 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         const unsigned raw = cur[2 * k + q];
         const unsigned v = __builtin_amdgcn_perm(from_left(raw), raw, sel);
         const unsigned win[3] = {from_left(v), v, from_right(v)};
-        hp[q][0] = hblur_px<0>(win);
-        hp[q][1] = hblur_px<1>(win);
-        hp[q][2] = hblur_px<2>(win);
-        hp[q][3] = hblur_px<3>(win);
+        hp[q][0] = hblur_px<0>(win, c128);
+        hp[q][1] = hblur_px<1>(win, c128);
+        hp[q][2] = hblur_px<2>(win, c128);
+        hp[q][3] = hblur_px<3>(win, c128);
       }
 #pragma unroll
       for (int p = 0; p < 4; p++) P[k][p] = hp[0][p] | (hp[1][p] << 16);
@@ -389,23 +396,24 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         unsigned ev[4], od[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-          ev[p] = __builtin_amdgcn_udot2(as_u16x2(A[p]), we0, 32768u, false);
+          ev[p] = __builtin_amdgcn_udot2(as_u16x2(A[p]), we0, 0u, false);  // the rounding term came with the rows (c128)
           ev[p] = __builtin_amdgcn_udot2(as_u16x2(B[p]), we1, ev[p], false);
           ev[p] = __builtin_amdgcn_udot2(as_u16x2(C[p]), we2, ev[p], false);
           ev[p] = __builtin_amdgcn_udot2(as_u16x2(D[p]), we3, ev[p], false);
-          od[p] = __builtin_amdgcn_udot2(as_u16x2(A[p]), wo0, 32768u, false);
+          od[p] = __builtin_amdgcn_udot2(as_u16x2(A[p]), wo0, 0u, false);
           od[p] = __builtin_amdgcn_udot2(as_u16x2(B[p]), wo1, od[p], false);
           od[p] = __builtin_amdgcn_udot2(as_u16x2(C[p]), wo2, od[p], false);
           od[p] = __builtin_amdgcn_udot2(as_u16x2(D[p]), wo3, od[p], false);
         }
         // every accumulator is < 2^24: the result pixel is its byte 2
         const unsigned oe = (__builtin_amdgcn_perm(ev[1], ev[0], 0x0c0c0602u) |
-                             (__builtin_amdgcn_perm(ev[3], ev[2], 0x0c0c0602u) << 16)) & keep;
+                             __builtin_amdgcn_perm(ev[3], ev[2], 0x06020c0cu)) & keep;
         const unsigned oo = (__builtin_amdgcn_perm(od[1], od[0], 0x0c0c0602u) |
-                             (__builtin_amdgcn_perm(od[3], od[2], 0x0c0c0602u) << 16)) & keep;
-        const int y = y0 + 2 * m - 6;
-        if (writes && y < h) *reinterpret_cast<unsigned *>(ldst + (unsigned)y * (unsigned)pitch) = oe;
-        if (writes && y + 1 < h) *reinterpret_cast<unsigned *>(ldst + (unsigned)(y + 1) * (unsigned)pitch) = oo;
+                             __builtin_amdgcn_perm(od[3], od[2], 0x06020c0cu)) & keep;
+        // output rows y0 + 2m - 6 and the next
+        __builtin_amdgcn_raw_buffer_store_b32(oe, rd, ooff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(oo, rd, ooff, pitch, 0);
+        ooff += 2u * (unsigned)pitch;
       }
     }
   }
