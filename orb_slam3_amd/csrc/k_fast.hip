@@ -333,29 +333,43 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const unsigned M = __builtin_amdgcn_readfirstlane((unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)nw)) + 1u);
     const int R = (int)((256u * M) >> 16);
     const int r0 = (int)(((unsigned)tid * M) >> 16), cq = qa + tid - r0 * nw;
-    const bool on = r0 < R;
-    const unsigned cm = colmask[cq];
-    const unsigned *tw = (LO ? tile : qtile) + r0 * FC_TP + cq;
-    const int step = R * FC_TP;
     QuickLane ql;
     ql.acc[0] = ql.acc[1] = 0;
     ql.e0 = ((unsigned)r0 << 8) | (unsigned)(4 * cq);
     ql.R = R;
-    int row = r0, top = 0;  // top: first row of the pass, wave-uniform
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
+    if (r0 < R) {  // (the lanes beyond R * nw idle)
+      const unsigned cm = colmask[cq];
+      const unsigned *tw = (LO ? tile : qtile) + r0 * FC_TP + cq;
+      const int step = R * FC_TP;
+      auto pass = [&](int k, unsigned acc) {
+        const unsigned hb = LO ? quick_quad<true>(tw, ka_lo) : quick_quad<false>(tw, ka_hi);
+        return acc | (((hb >> 7) & cm) << k);
+      };
+      // nf passes whose R rows all exist (no row test inside the loops, one exit each), then the last one
+      // nf = (nrow - 1) / R, by the same kind of reciprocal (63 * 2 * R < 65536)
+      const unsigned MR = __builtin_amdgcn_readfirstlane((unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)R)) + 1u);
+      const int nf = (int)(((unsigned)(nrow - 1) * MR) >> 16);
+      const int n0 = min(nf, 8);
       unsigned acc = 0;
 #pragma unroll 1
-      for (int k = 0; k < 8 && top < nrow; k++) {
-        if (on && row < nrow) {
-          const unsigned hb = LO ? quick_quad<true>(tw, ka_lo) : quick_quad<false>(tw, ka_hi);
-          acc |= ((hb >> 7) & cm) << k;
-        }
-        row += R;
-        top += R;
+      for (int k = 0; k < n0; k++) {
+        acc = pass(k, acc);
         tw += step;
       }
-      ql.acc[kb] = acc;
+      if (nf < 8) {
+        if (r0 < nrow - nf * R) acc = pass(nf, acc);
+        ql.acc[0] = acc;
+      } else {
+        ql.acc[0] = acc;
+        acc = 0;
+#pragma unroll 1
+        for (int k = 8; k < nf; k++) {
+          acc = pass(k - 8, acc);
+          tw += step;
+        }
+        if (r0 < nrow - nf * R) acc = pass(nf - 8, acc);
+        ql.acc[1] = acc;
+      }
     }
     return ql;
   };
