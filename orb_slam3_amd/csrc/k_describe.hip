@@ -248,18 +248,33 @@ __global__ __launch_bounds__(64 * KPB) void k_describe(const uint8_t *__restrict
     const int l = lv[h];
     const int pos = total - 1 - ((l ? s_prefix[l - 1] : 0) + idx[h]);  // reversed packing, SURVEY App. B.4
     const float a = s_cs[wave * KPW + h][0], b = s_cs[wave * KPW + h][1];
-    // ---- rotated BRIEF: taps = cvRound(x*b + y*a), cvRound(x*a - y*b), float32 without FMA
-    const uint8_t *P8 = reinterpret_cast<const uint8_t *>(patch[wave * KPW + h]) + PR * PPITCH + PR + sh[h];
+    // ---- rotated BRIEF: taps = cvRound(x*b + y*a), cvRound(x*a - y*b), float32 without FMA.  Row and column of a tap
+    //      side by side in packed f32 operations (each half is the IEEE operation of the scalar form; x*a - y*b is
+    //      x*a + y*(-b) bit for bit), and cvRound as the addition of 1.5 * 2^23: the sum's ulp is 1 there, so the
+    //      addition rounds to the nearest even integer as v_rndne does, and the integer sits in the low mantissa bits
+    //      -- the constant's own bits go into the address with the patch's base (tap_addr).
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f ba = {b, a}, anb = {a, -b}, magic = {12582912.0f, 12582912.0f};
+    const unsigned p8 = (unsigned)reinterpret_cast<size_t>(patch[wave * KPW + h]) + PR * PPITCH + PR + sh[h];
+    // low 24 bits of the row's float = 0x400000 + r, the column's float = 0x4B400000 + c
+    const unsigned tap_base = p8 - (0x400000u * PPITCH + 0x4B400000u);
+    // xy = (x, y) as it lies in the pattern's register pair: the products take x / y for both halves through op_sel
+    // (written out: for the y broadcast the compiler copies y into another pair first)
+    auto tap = [&](v2f xy) -> int {
+      v2f xb, ya;
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(xb) : "v"(xy), "v"(ba));               // (x * b, x * a)
+      asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(ya) : "v"(xy), "v"(anb));  // (y * a, y * -b)
+      const v2f rc = (xb + ya) + magic;
+      const float fr = rc.x, fc = rc.y;  // (__builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+      const unsigned addr = tap_base + (unsigned)(__mul24(__float_as_int(fr), PPITCH) + __float_as_int(fc));
+      return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(addr);
+    };
     unsigned long long bits[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const float4 pt = ptn[q];
-      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
-      const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
-      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
-      const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
-      const int t0 = P8[r0 * PPITCH + c0];
-      const int t1 = P8[r1 * PPITCH + c1];
+      const int t0 = tap(v2f{pt.x, pt.y});
+      const int t1 = tap(v2f{pt.z, pt.w});
       bits[q] = __ballot(t0 < t1);  // bit k of byte i = test 8i + k: ballot order is the descriptor's byte order
     }
     if (lane == 0) {

@@ -203,22 +203,6 @@ __host__ __device__ constexpr size_t fast_cells_lds_bytes(int rows) {
          + 16;
 }
 
-// inclusive prefix sum over the 64 lanes of a wave: four row_shr steps inside each 16-lane row, then the row totals
-// travel with row_bcast:15 / row_bcast:31 (lanes without a source add 0)
-// Written out: from update_dpp + add the compiler makes v_mov 0 / v_mov_dpp / v_add, three instructions a step; the add
-// takes the shifted operand itself (a lane without a source is not written and keeps its own value).  s_nop 1: the two
-// wait states between a vector write and a DPP read of the same register.
-__device__ __forceinline__ int wave_incl_scan(int v) {
-  asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
-      : "+v"(v));
-  return v;
-}
-
 // PART only names the instantiation: 0 = the launch the roofline is quoted on (levels >= 1, or all levels), 1 = the
 // launch for level 0, which runs on the second stream beside the resize chain (profilers keep the two apart by name)
 template <bool DUMP, int PART = 0>

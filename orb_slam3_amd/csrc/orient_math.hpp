@@ -7,6 +7,7 @@
 #include <cfloat>
 
 #include "orbgpu_internal.h"
+#include "tile_stage.hpp"
 
 namespace orient {
 
@@ -110,11 +111,9 @@ __device__ __forceinline__ void orient_angles(const unsigned (&ov)[NK][5], const
       m01 += (7 * k + osub - ORB_HALF_PATCH) * (int)rs;
     }
     int m10 = (int)a10 - ORB_HALF_PATCH * (int)si;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      m10 += __shfl_xor(m10, off);
-      m01 += __shfl_xor(m01, off);
-    }
+    // the wave's sums end up in lane 63 (six DPP adds each; a ds_bpermute butterfly is 18 instructions and 6 LDS ops)
+    m10 = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);
+    m01 = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
     ang[h] = fast_atan2_deg((float)m01, (float)m10);
   }
 }
