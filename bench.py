@@ -554,6 +554,7 @@ def main():
         for row in csv.DictReader(open(sfile)):
             if want in row.get("Name", ""):
                 rocprof_ms = round(float(row["AverageNs"]) * 1e-6, 4)
+    fast_valu = float(sq.get(fast_kernel, {}).get("SQ_INSTS_VALU", 0.0))
     roofline = {"bound": "hbm", "kernel": fast_kernel, "achieved": round(fast_gbs, 2), "peak": hbm_peak,
                 "unit": "GB/s", "frac": round(fast_gbs / hbm_peak, 5), "traffic": traffic,
                 "avg_launch_ms": round(st[1], 4), "bytes_per_launch": P_fast * B, "traffic_source": traffic_src,
@@ -566,11 +567,11 @@ def main():
                            "the same kernel (k_fast_cells<false,1>, pipeline.fast_level0) that needs no pyramid and runs "
                            "beside the resize chain") if early_l0 else "all pyramid levels of every frame",
                 "limiter": "not HBM (the counters show 0.96 x the algorithmic bytes, once): vector-instruction issue. The "
-                           "kernel (FAST score + per-cell NMS, fallback and compaction, fused) executes 1.05e8 wave "
-                           "instructions per launch on the vector ALU (round 2: 1.25e8; "
+                           "kernel (FAST score + per-cell NMS, fallback and compaction, fused) executes "
+                           f"{fast_valu:.3g} wave instructions per launch on the vector ALU (round 2: 1.25e8; "
                            "profiles/r3_hbm_traffic.json sq_counters_per_launch), and at the 4 clocks a SIMD needs for one "
-                           "wave64 instruction of this mix that alone is 0.19 ms at 2.2 GHz; the rest of a workgroup's 7.8 us "
-                           "is the latency of its tile load (DESIGN.md, 'Round 3: k_fast_cells')"}
+                           f"wave64 instruction that alone is {fast_valu * 4 / 1024 / 2.2e9 * 1e3:.3f} ms at 2.2 GHz; the rest "
+                           "is the latency of a workgroup's tile load and its barriers (DESIGN.md, 'Round 3: k_fast_cells')"}
     # whole extraction against SURVEY 8d's per-frame figure A = 5P - px0 - px7 + 1978 N
     A = 5 * P - g.w[0] * g.h[0] - g.w[g.levels - 1] * g.h[g.levels - 1] + 1978 * NF
     ext_s = st[6] * 1e-3
