@@ -63,6 +63,33 @@ __device__ __forceinline__ void sincos_short(double x, double &sn, double &cs) {
   cs = q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
 }
 
+// ---- one tap of the rotated BRIEF pattern: cvRound(x*b + y*a) rows and cvRound(x*a - y*b) columns from the patch
+//      centre (computeOrbDescriptor :120-165; float32 without FMA), read from a byte patch in LDS with rows of PITCH
+//      bytes.  Row and column side by side in packed f32 operations (each half is the IEEE operation of the scalar form;
+//      x*a - y*b is x*a + y*(-b) bit for bit), and cvRound as the addition of 1.5 * 2^23: the sum's ulp is 1 there, so the
+//      addition rounds to the nearest even integer as v_rndne does, and the integer sits in the low mantissa bits --
+//      the constant's own bits go into the address with the patch's base (tap_base_of).
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct TapRot { v2f ba, anb; };  // (sin, cos), (cos, -sin)
+__device__ __forceinline__ TapRot tap_rot(float a /* cos */, float b /* sin */) { return TapRot{v2f{b, a}, v2f{a, -b}}; }
+// centre: LDS address of the patch's centre byte.  low 24 bits of the row's float = 0x400000 + r, the column's float =
+// 0x4B400000 + c
+template <int PITCH>
+__device__ __forceinline__ unsigned tap_base_of(unsigned centre) { return centre - (0x400000u * PITCH + 0x4B400000u); }
+// xy = (x, y) as it lies in the pattern's register pair: the products take x / y for both halves through op_sel
+// (written out: for the y broadcast the compiler copies y into another pair first)
+template <int PITCH>
+__device__ __forceinline__ int brief_tap(v2f xy, const TapRot &rot, unsigned tap_base) {
+  const v2f magic = {12582912.0f, 12582912.0f};
+  v2f xb, ya;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(xb) : "v"(xy), "v"(rot.ba));                // (x * b, x * a)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(ya) : "v"(xy), "v"(rot.anb));  // (y * a, y * -b)
+  const v2f rc = (xb + ya) + magic;
+  const float fr = rc.x, fc = rc.y;  // (__builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
+  const unsigned addr = tap_base + (unsigned)(__mul24(__float_as_int(fr), PITCH) + __float_as_int(fc));
+  return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(addr);
+}
+
 constexpr int PR = 18;              // patch radius staged for the descriptor: the pattern's points lie within 18.385 px
                                     // of the centre (13, 13), so a rotated tap rounds to at most 18
 constexpr int PW = 2 * PR + 1;      // 37 rows
@@ -248,33 +275,16 @@ __global__ __launch_bounds__(64 * KPB) void k_describe(const uint8_t *__restrict
     const int l = lv[h];
     const int pos = total - 1 - ((l ? s_prefix[l - 1] : 0) + idx[h]);  // reversed packing, SURVEY App. B.4
     const float a = s_cs[wave * KPW + h][0], b = s_cs[wave * KPW + h][1];
-    // ---- rotated BRIEF: taps = cvRound(x*b + y*a), cvRound(x*a - y*b), float32 without FMA.  Row and column of a tap
-    //      side by side in packed f32 operations (each half is the IEEE operation of the scalar form; x*a - y*b is
-    //      x*a + y*(-b) bit for bit), and cvRound as the addition of 1.5 * 2^23: the sum's ulp is 1 there, so the
-    //      addition rounds to the nearest even integer as v_rndne does, and the integer sits in the low mantissa bits
-    //      -- the constant's own bits go into the address with the patch's base (tap_addr).
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const v2f ba = {b, a}, anb = {a, -b}, magic = {12582912.0f, 12582912.0f};
-    const unsigned p8 = (unsigned)reinterpret_cast<size_t>(patch[wave * KPW + h]) + PR * PPITCH + PR + sh[h];
-    // low 24 bits of the row's float = 0x400000 + r, the column's float = 0x4B400000 + c
-    const unsigned tap_base = p8 - (0x400000u * PPITCH + 0x4B400000u);
-    // xy = (x, y) as it lies in the pattern's register pair: the products take x / y for both halves through op_sel
-    // (written out: for the y broadcast the compiler copies y into another pair first)
-    auto tap = [&](v2f xy) -> int {
-      v2f xb, ya;
-      asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(xb) : "v"(xy), "v"(ba));               // (x * b, x * a)
-      asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(ya) : "v"(xy), "v"(anb));  // (y * a, y * -b)
-      const v2f rc = (xb + ya) + magic;
-      const float fr = rc.x, fc = rc.y;  // (__builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler)
-      const unsigned addr = tap_base + (unsigned)(__mul24(__float_as_int(fr), PPITCH) + __float_as_int(fc));
-      return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(addr);
-    };
+    // ---- rotated BRIEF (brief_tap)
+    const TapRot rot = tap_rot(a, b);
+    const unsigned tap_base =
+        tap_base_of<PPITCH>((unsigned)reinterpret_cast<size_t>(patch[wave * KPW + h]) + PR * PPITCH + PR + sh[h]);
     unsigned long long bits[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const float4 pt = ptn[q];
-      const int t0 = tap(v2f{pt.x, pt.y});
-      const int t1 = tap(v2f{pt.z, pt.w});
+      const int t0 = brief_tap<PPITCH>(v2f{pt.x, pt.y}, rot, tap_base);
+      const int t1 = brief_tap<PPITCH>(v2f{pt.z, pt.w}, rot, tap_base);
       bits[q] = __ballot(t0 < t1);  // bit k of byte i = test 8i + k: ballot order is the descriptor's byte order
     }
     if (lane == 0) {
@@ -431,11 +441,8 @@ __global__ __launch_bounds__(64 * FKPB) void k_patch_describe(const uint8_t *__r
       m01 += (row - ORB_HALF_PATCH) * (int)rs;
     }
     int m10 = (int)a10 - ORB_HALF_PATCH * (int)si;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      m10 += __shfl_xor(m10, off);
-      m01 += __shfl_xor(m01, off);
-    }
+    m10 = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);  // (as orient_angles)
+    m01 = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
     ang[h] = fast_atan2_deg((float)m01, (float)m10);
   }
   // ---- cos / sin of the wave's keypoints, keypoint h on lane h (float(angle_deg) * (double)(pi / 180) -> float, cos / sin
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(64 * FKPB) void k_patch_describe(const uint8_t *__r
           const unsigned v0 = vblur_px(A.x, B.x, C.x, D.x, vodd), v1 = vblur_px(A.y, B.y, C.y, D.y, vodd);
           const unsigned v2 = vblur_px(A.z, B.z, C.z, D.z, vodd), v3 = vblur_px(A.w, B.w, C.w, D.w, vodd);
           // every accumulator is < 2^24: the result pixel is its byte 2
-          R[(yr + 3) * QDW + d] = __builtin_amdgcn_perm(v1, v0, 0x0c0c0602u) | (__builtin_amdgcn_perm(v3, v2, 0x0c0c0602u) << 16);
+          R[(yr + 3) * QDW + d] = __builtin_amdgcn_perm(v1, v0, 0x0c0c0602u) | __builtin_amdgcn_perm(v3, v2, 0x06020c0cu);
         }
         d += 10;
         jr += 2;
@@ -516,17 +523,14 @@ __global__ __launch_bounds__(64 * FKPB) void k_patch_describe(const uint8_t *__r
     // ---- rotated BRIEF on the blurred core (computeOrbDescriptor :120-165), as k_describe ----------------------------
     const int l = lv[h];
     const int pos = total - 1 - ((l ? __builtin_amdgcn_readlane(pre, max(l - 1, 0)) : 0) + idx[h]);  // reversed packing, App. B.4
-    const uint8_t *P8 = reinterpret_cast<const uint8_t *>(R) + QR * QPITCH + QR + sh[h];
+    const TapRot rot = tap_rot(a, b);
+    const unsigned tap_base = tap_base_of<QPITCH>((unsigned)reinterpret_cast<size_t>(R) + QR * QPITCH + QR + sh[h]);
     unsigned long long bits[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const float4 pt = ptn[q];
-      const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
-      const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
-      const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
-      const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
-      const int t0 = P8[r0 * QPITCH + c0];
-      const int t1 = P8[r1 * QPITCH + c1];
+      const int t0 = brief_tap<QPITCH>(v2f{pt.x, pt.y}, rot, tap_base);
+      const int t1 = brief_tap<QPITCH>(v2f{pt.z, pt.w}, rot, tap_base);
       bits[q] = __ballot(t0 < t1);
     }
     if (lane == 0) {
