@@ -16,13 +16,7 @@
 
 namespace {
 
-// three-input min / max, pinned: left to itself the compiler shares two-input partial results between neighbouring
-// windows and ends up with twice as many instructions
-__device__ __forceinline__ int vmin3(int a, int b, int c) {
-  int r;
-  asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// three-input max, pinned (the NMS neighbourhood)
 __device__ __forceinline__ int vmax3(int a, int b, int c) {
   int r;
   asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -96,21 +90,6 @@ __device__ __forceinline__ int fast_score16_full(int v, const unsigned (&P)[8], 
   return s >= min_thr ? s : 0;
 }
 
-typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
-
-__device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
-__device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
-
-// bytes b and b+1 of the 12-byte window {w0,w1,w2} zero-extended into the two u16 halves
-template <int B>
-__device__ __forceinline__ u16x2 pair_bytes(const unsigned (&w)[3]) {
-  constexpr int lo = B >> 2;
-  constexpr int k0 = B & 3, k1 = k0 + 1;  // byte positions inside the 8-byte pool {w[lo+1], w[lo]}
-  constexpr unsigned sel = (unsigned)k0 | (0x0cu << 8) | ((unsigned)k1 << 16) | (0x0cu << 24);
-  const unsigned hi = (lo + 1 < 3) ? w[lo + 1 < 3 ? lo + 1 : 2] : 0u;
-  return as_u16x2(__builtin_amdgcn_perm(hi, w[lo], sel));
-}
-
 // Quick test of the 4 pixels of a quad on bytes, without widening: pixels quantised to 6 bits (p >> 2) leave two
 // spare bits per byte, so with a = (t + 1) >> 2 the byte-wise sums v6 + (128 - a) - r6 and r6 + (128 - a) - v6 neither
 // borrow nor carry across bytes and have bit 7 set exactly when v6 - r6 >= a / r6 - v6 >= a.  A corner at threshold t has
@@ -159,12 +138,14 @@ __device__ __forceinline__ unsigned quick_quad(const unsigned *tw, unsigned ka) 
 //   phase 1  quick test at iniThFAST on bytes (quick_quad: 4 pixels per operation on the quantised tile, conservative),
 //            a lane keeps its quad column and walks down the rows; survivor bits collect in a register;
 //   push     survivors -> LDS queue as (row, column), one wave scan + one LDS atomic per wave;
-//   phase 2  full 9-arc score per survivor -> score tile in LDS (zero apron);
+//   phase 2  full 9-arc score per survivor (fast_score16_full: packed 3-input min / max on the ring pixels) -> score
+//            tile in LDS (zero apron);
 //   phase 3  3x3 NMS per scored pixel, neighbours outside the pixel's own cell masked; survivors set a bit in their
-//            cell's row mask, one mask for "kept" and one for "kept and >= iniThFAST";
+//            cell's row mask;
 //   phase 4  one wave per cell: survivors written in raster order to the cell's fixed slot of the candidate pool;
 //   then, only if a cell kept nothing (orb_feature_extractor.cpp:263-266: decided per cell AFTER NMS): a second quick
-//            test at minThFAST over the columns of those cells, score, NMS and emit for them.
+//            test at minThFAST over the columns of those cells (the queue refilled from its front), score, NMS and
+//            emit for them.
 // No score map, no bit plane and no second kernel: the only global traffic is the tile read and the candidates.
 // DUMP = true additionally scatters the non-zero scores into a global score map (orbgpu_debug_dump's stage test).
 struct FastGroup { short level, row, j0, ncell; };
