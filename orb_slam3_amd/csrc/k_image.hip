@@ -150,12 +150,7 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 // one v_dot2_u32_u16 against (a0, a1) << 4.  The blend of the previous source row stays in registers, so an output
 // row costs one vertical pass: (b0 * (h0 >> 4)) >> 16 is v_mul_hi_u32_u24 of (b0 << 8) and ((h << 4) & ~255).
 // Row control (which output rows a source row completes) is scalar: the wave's lanes share their rows.
-__device__ __forceinline__ unsigned mulhi24u(unsigned a, unsigned b) {
-  unsigned d;
-  asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-// the same with a wave-uniform first factor straight from its scalar register
+// v_mul_hi_u32_u24 with a wave-uniform first factor straight from its scalar register
 __device__ __forceinline__ unsigned mulhi24u_s(unsigned a_uniform, unsigned b) {
   unsigned d;
   asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(d) : "s"(a_uniform), "v"(b));

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256) void k_link_partial(const orbgpu_keypoint *__r
   const int ft = to_frame[p], ff = from_frame[p];
   const int n_to = usable_count(n_kp[ft], capacity), n_from = usable_count(n_kp[ff], capacity);
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= n_to) return;
+  if ((int)(blockIdx.x * 256) >= n_to) return;
   const int j0 = blockIdx.y * chunk, j1 = min(j0 + chunk, n_from);
   const int ii = min(i, n_to - 1);
   const orbgpu_keypoint *fk = kp + (size_t)ff * capacity;

@@ -867,7 +867,7 @@ __global__ __launch_bounds__(NT) void k_quadtree(DeviceGeom g, QtArgs a) {
   const CellEntry *cells = a.cells + (size_t)f * g.cells_per_frame + L.cell_off;
   int *cpre = a.cell_prefix + (size_t)f * g.cells_per_frame + L.cell_off;
   int n = 0;
-  const int R = blockIdx.y < a.ps_levels ? a.ps_depth[l] : 0;
+  const int R = (int)blockIdx.y < a.ps_levels ? a.ps_depth[l] : 0;
   if (R > 0) {
     const unsigned *hpre = a.ps + ((size_t)f * a.ps_levels + l) * PS_STRIDE + (size_t)PS_CHUNKS * PS_NB_MAX;
     n = (int)hpre[a.nini[l] << (2 * R)];

@@ -194,3 +194,35 @@ def test_bench_gpus_flag_starts_that_many_ranks():
         r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--frames", "8"], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "rank exit codes" in r.stderr
+
+
+def test_kernel_reciprocal_divisions_are_exact():
+    """k_fast_cells (csrc/k_fast.hip, quick_round) divides by a 16-bit reciprocal: with M = floor(65536 / d) + 1 or + 2
+    (v_rcp_f32's estimate of 65536 / d is within 0.02 of it) it takes n * M >> 16 for n / d.  Exhaustive over the
+    ranges the kernel uses: thread id / quads per row (d <= 36, n < 256), 256 / quads per row, and
+    (rows - 1) / rows per pass (d <= 256, n <= 63)."""
+    for d in range(1, 37):
+        for M in (65536 // d + 1, 65536 // d + 2):
+            for n in range(0, 257):
+                assert (n * M) >> 16 == n // d, (n, d, M)
+    for d in range(1, 257):
+        for M in (65536 // d + 1, 65536 // d + 2):
+            for n in range(0, 64):
+                assert (n * M) >> 16 == n // d, (n, d, M)
+
+
+def test_packed_score_network_identity():
+    """k_fast_cells scores a pixel from the ring pixels themselves (fast_score16_full): with d = v - ring,
+    max over arcs of min(d) = v - min over arcs of max(ring) and max over arcs of min(-d) = max over arcs of min(ring) - v.
+    Checked against the definition on random rings."""
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        ring = rng.integers(0, 256, 16)
+        v = int(rng.integers(0, 256))
+        d = v - ring
+        arcs = [[(k + i) % 16 for i in range(9)] for k in range(16)]
+        m_dark = max(min(d[a]) for a in arcs)
+        m_bright = max(min(-d[a]) for a in arcs)
+        a_min = min(max(ring[a]) for a in arcs)
+        b_max = max(min(ring[a]) for a in arcs)
+        assert m_dark == v - a_min and m_bright == b_max - v
