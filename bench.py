@@ -381,9 +381,12 @@ def main():
         dt3 = float(t3.item())
         input_ready = {"frames_per_s": round(world * B * args.steps / dt3, 1), "ms_per_step": round(dt3 / args.steps * 1e3, 3),
                        "steps": args.steps,
-                       "what": "the timed loop's steps on one context after orbgpu_set_input_ready(ctx, 1, NULL): a call's "
-                               "pyramid and FAST kernels run on a stream of their own beside the previous call's descriptor "
-                               "and link kernels; max over ranks"}
+                       "what": "the timed loop's steps on one context after orbgpu_set_input_ready(ctx, 1, NULL): the calls "
+                               "alternate between the context's two working sets (pyramid, cells, candidates) and a call's "
+                               "pyramid and FAST kernels run on a stream of their own beside the previous call's quadtree, "
+                               "orientation, descriptor and link kernels; max over ranks.  In a process that holds no other "
+                               "streams the same loop takes 0.68 ms per step (tools/piped_probe.py): which streams share one "
+                               "of the 4 hardware queues decides"}
 
 
     # ---- SURVEY 8e / BASELINE.json configs[4]: cross-shard all-pairs keyframe matching -------------------------
@@ -437,10 +440,13 @@ def main():
         # that starts on a multiple of the batch size is one slice and is extracted in place
         resident = ResidentSource(pooled, dev, repeat=max(1, B // pooled.pool.shape[0]))
         for leg, src in (("pcie_inclusive", pooled), ("hbm_resident", resident)):
-            # two contexts where the extraction is the bound (frames resident), one where PCIe is
-            two = leg == "hbm_resident" and not args.one_context
-            fe_b = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, device=local_rank, max_batch=B, max_features=NF) if two else None
-            runner = SequenceRunner([fe, fe_b] if two else fe, src, NF, keyframe_every=10)
+            # where the extraction is the bound (frames resident) the runner gives the library the input-ready hint: the
+            # batches alternate between the context's two working sets and batch k + 1's pyramid and FAST run beside batch
+            # k's tail (363 k frames/s against 311 k without the hint and 304-329 k with two contexts alternating, whose
+            # extra streams share hardware queues); where PCIe is the bound the hint costs 8 % (the head stream then
+            # shares a hardware queue with the upload stream) and is left off
+            hint = leg == "hbm_resident" and not args.one_context
+            runner = SequenceRunner(fe, src, NF, keyframe_every=10, input_ready=hint)
             runner.run(min(n_seq, 3 * B), rank, world)            # warm-up: scratch, ring, events
             best = None
             for it in range(2):
@@ -456,14 +462,14 @@ def main():
             legs[leg] = {"seconds": round(sec, 4), "frames_per_s": round(n_seq / sec, 1),
                          "frames_extracted_rank0": res.timing["frames_extracted"], "batches_rank0": res.timing["batches"],
                          "host_enqueue_seconds_rank0": round(res.timing["enqueue_seconds"], 4),
-                         "contexts_per_rank": 2 if two else 1}
+                         "contexts_per_rank": 1, "input_ready_hint": hint}
             if leg == "pcie_inclusive":
                 legs[leg]["upload_GBps_per_gpu"] = round(res.timing["bytes_uploaded"] / sec / 1e9, 2)
                 legs[leg]["source"] = "64 procedural frames in pinned host memory, frame i = pool[i % 64]; every frame crosses PCIe"
                 kf_result, kf_runner = res, runner
             del runner
-            if two:                                              # the sections below run with one context, as before
-                fe_b.close()
+            if hint:                                             # second working set and head stream go back
+                check(lib.orbgpu_trim(fe.handle))
         # all-pairs over the keyframes of the PCIe leg's result: the popcount kernel (the contract path, the figures below),
         # then the same call on the exploratory i8 matrix-core engine, asserted identical
         barrier()

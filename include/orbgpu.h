@@ -95,11 +95,13 @@ int orbgpu_synchronize(orbgpu_ctx *ctx);
  * By default the kernels of an extract call start behind everything already enqueued on the context's stream -- which is
  * also how they see the caller's images.  With ready != 0 the caller promises that the images of every later
  * orbgpu_extract_batch_device call are complete when the call is made, or, with a non-null `event` (a hipEvent_t), when
- * that event has fired (call this before each extract to name the batch's own event).  The library then runs the call's
- * pyramid and FAST kernels on a stream of its own as soon as the previous call has read its pyramid for the last time --
- * beside the previous batch's descriptor kernel and whatever the caller enqueued behind it (the link) -- and keeps
- * everything from the quadtree on, and so the outputs, in the context's stream order.  Applies to images that are
- * read in place (orbgpu_extract_batch_device's layout rule) with the full-frame blur; other calls run as before.
+ * that event has fired (call this before each extract to name the batch's own event).  The library then keeps what a
+ * call's first kernels write (pyramid, FAST cells, candidates) twice, lets such calls alternate between the two working
+ * sets, and runs a call's pyramid and FAST kernels on a stream of its own -- beside the previous batch's quadtree,
+ * orientation and descriptor kernels and whatever the caller enqueued behind them (the link) -- while everything from
+ * the quadtree on, and so the outputs, stays in the context's stream order.  The second working set (as large as the
+ * pyramid slab) is allocated by the first such call and given back by orbgpu_trim.  Applies to images that are read in
+ * place (orbgpu_extract_batch_device's layout rule) with the full-frame blur; other calls run as before.
  * ready == 0 (the default) restores the plain stream order. */
 int orbgpu_set_input_ready(orbgpu_ctx *ctx, int32_t ready, void *event);
 

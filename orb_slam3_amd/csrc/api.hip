@@ -229,7 +229,14 @@ void release_side_streams(orbgpu_ctx *ctx) {
     (void)hipStreamDestroy(ctx->head_stream);
     ctx->head_stream = nullptr;
   }
-  ctx->head_ok_valid = false;  // (the context's stream is drained by every caller of this function)
+  // (the context's stream is drained by every caller of this function: both working sets are idle, the second goes back)
+  ctx->set_state[0] = ctx->set_state[1] = orbgpu_ctx::SET_IDLE;
+  void *alt[3] = {ctx->d_pyr_alt, ctx->d_cells_alt, ctx->d_cands_alt};
+  for (void *q : alt)
+    if (q) (void)hipFree(q);
+  ctx->d_pyr_alt = nullptr;
+  ctx->d_cells_alt = nullptr;
+  ctx->d_cands_alt = nullptr;
   for (int k = 0; k < orbgpu_ctx::MAX_SLICES; k++) {
     hipStream_t *st[3] = {&ctx->slice_stream[k], &ctx->slice_blur[k], &ctx->slice_l0[k]};
     for (hipStream_t *q : st)
@@ -279,8 +286,6 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   level_budget(ctx->params.scale_factor, L, feature_count, budget);
   // the device error flag is sticky: it is only cleared by finish_pipeline(), so queued calls cannot hide an error
   hipEvent_t *ev = ctx->ev[ctx->ev_head];
-  const bool head_ok_prev = ctx->head_ok_valid;  // (an early return below leaves it off)
-  ctx->head_ok_valid = false;
   int n_slices = ctx->n_slices > 0 ? ctx->n_slices : 1;
   n_slices = std::max(1, std::min(std::min(n_slices, (int)orbgpu_ctx::MAX_SLICES), n_frames));
   // an event between two kernels of a stream costs 6-7 us of stream time: by default only the FAST kernel is bracketed
@@ -294,7 +299,6 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
   for (int s = 0; s < n_slices; s++) {
     const int f0 = (int)((long long)n_frames * s / n_slices), f1 = (int)((long long)n_frames * (s + 1) / n_slices);
     const FrameSlice fs{f0, f1 - f0, s == 0 ? ctx->stream : ctx->slice_stream[s]};
-    bool head_ok_here = false;
     const FrameSlice fb{f0, f1 - f0, ctx->no_overlap ? fs.stream : ctx->slice_blur[s]};
     hipEvent_t *sev = ctx->slice_ev[s];
     const bool timed = s == 0 && stage_timing;       // the stage timers follow slice 0
@@ -305,19 +309,46 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     const int E = ctx->early_l0 ? std::min(ctx->early_levels, L - 1) : 0;
     const FrameSlice fl{f0, f1 - f0, ctx->no_overlap ? fs.stream : ctx->slice_l0[s]};
     // orbgpu_set_input_ready: the head (pyramid + FAST) of this call on a stream that does not wait for the context's
-    // stream -- the previous batch's descriptor and link kernels are gathers that wait on memory, the head is vector-ALU
-    // work -- but for the caller's input event and for the event the previous call recorded where it had read its
-    // pyramid, cells and candidates for the last time (behind orientation and blur).  Everything from the quadtree on
-    // stays on the context's stream, behind the head's end.
+    // stream -- the previous batch's quadtree, orientation, descriptor and link kernels are chains of short rounds and
+    // gathers that wait on memory, the head is vector-ALU work.  It writes the OTHER working set, so it waits only for
+    // the caller's input event and for the event recorded where that set was read for the last time (by the call before
+    // the previous one, behind its orientation and blur).  Everything from the quadtree on stays on the context's
+    // stream, behind the head's end.
     const bool patch = patch_mode(ctx, feature_count);
-    const bool piped = ctx->call_piped && head_ok_prev && n_slices == 1 && !capture && !stage_timing &&
-                       !ctx->no_overlap && !patch;
+    bool piped = ctx->call_piped && n_slices == 1 && !capture && !stage_timing && !ctx->no_overlap && !patch &&
+                 ctx->set_state[1 - ctx->work_set] != orbgpu_ctx::SET_BUSY;
+    if (piped && !ctx->d_pyr_alt) {  // the second working set, on first use (a failed allocation: the call runs unpiped)
+      const size_t B = (size_t)ctx->params.max_batch;
+      uint8_t *pyr = nullptr;
+      CellEntry *cells = nullptr;
+      unsigned *cands = nullptr;
+      if (dmalloc(&pyr, B * g.frame_bytes + 256) == hipSuccess && dmalloc(&cells, B * g.cells_per_frame) == hipSuccess &&
+          dmalloc(&cands, B * g.cands_per_frame) == hipSuccess &&
+          hipMemset(pyr, 0, B * g.frame_bytes + 256) == hipSuccess) {
+        ctx->d_pyr_alt = pyr;
+        ctx->d_cells_alt = cells;
+        ctx->d_cands_alt = cands;
+      } else {
+        (void)hipGetLastError();
+        if (pyr) (void)hipFree(pyr);
+        if (cells) (void)hipFree(cells);
+        if (cands) (void)hipFree(cands);
+        piped = false;
+      }
+    }
     if (piped) {
       if (!ctx->head_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->head_stream, hipStreamNonBlocking));
       if (!ctx->ev_head_done) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_head_done, hipEventDisableTiming));
+      std::swap(ctx->d_pyr, ctx->d_pyr_alt);
+      std::swap(ctx->d_cells, ctx->d_cells_alt);
+      std::swap(ctx->d_cands, ctx->d_cands_alt);
+      ctx->work_set = 1 - ctx->work_set;
       if (ctx->input_event) HIP_TRY(hipStreamWaitEvent(ctx->head_stream, ctx->input_event, 0));
-      HIP_TRY(hipStreamWaitEvent(ctx->head_stream, ctx->ev_head_ok, 0));
+      if (ctx->set_state[ctx->work_set] == orbgpu_ctx::SET_EVENT)
+        HIP_TRY(hipStreamWaitEvent(ctx->head_stream, ctx->ev_set_free[ctx->work_set], 0));
     }
+    // until the event below is recorded the set is in use by whatever this call enqueues
+    ctx->set_state[ctx->work_set] = orbgpu_ctx::SET_BUSY;
     const FrameSlice fh{f0, f1 - f0, piped ? ctx->head_stream : fs.stream};
     if (E > 0) {
       HIP_TRY(hipEventRecord(sev[3], fh.stream));  // after everything already on the stream (the caller's images included)
@@ -385,10 +416,11 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
       HIP_TRY(hipEventRecord(sev[1], fb.stream));
       HIP_TRY(hipStreamWaitEvent(fs.stream, sev[1], 0));
       if (timed) HIP_TRY(hipEventRecord(ev[5], fs.stream));
-      if (s == n_slices - 1 && n_slices == 1 && !capture) head_ok_here = true;
-      if (head_ok_here) {
-        if (!ctx->ev_head_ok) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_head_ok, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ctx->ev_head_ok, fs.stream));  // pyramid, cells and candidates have been read for the last time
+      if (n_slices == 1 && !capture) {  // pyramid, cells and candidates of this call's set have been read for the last time
+        hipEvent_t &free_ev = ctx->ev_set_free[ctx->work_set];
+        if (!free_ev) HIP_TRY(hipEventCreateWithFlags(&free_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(free_ev, fs.stream));
+        ctx->set_state[ctx->work_set] = orbgpu_ctx::SET_EVENT;
       }
       launch_describe(ctx, fs, d_kp, d_desc, capacity, d_n_out);
     }
@@ -399,8 +431,6 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     }
   }
   if (stage_timing) HIP_TRY(hipEventRecord(ev[9], ctx->stream));  // every slice has finished
-  // the next call's head may start behind ev_head_ok only if this call recorded it (one slice, full-frame blur, no capture)
-  ctx->head_ok_valid = n_slices == 1 && !capture && !ctx->last_patch_mode && ctx->ev_head_ok != nullptr;
   HIP_TRY(hipGetLastError());
   ctx->last_frames = n_frames;
   ctx->last_feature_count = feature_count;
@@ -418,6 +448,8 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
 // waits for the stream, turns the device error flag into a status and reads the stage timers
 int finish_pipeline(orbgpu_ctx *ctx) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  // every head has been joined into the context's stream: nothing enqueued uses either working set any more
+  ctx->set_state[0] = ctx->set_state[1] = orbgpu_ctx::SET_IDLE;
   if (ctx->ev_pending > 0) {
     // stage times: mean over the extract calls enqueued since the last synchronisation (at most ORBGPU_EV_SETS)
     const int n = ctx->ev_pending;
@@ -575,7 +607,8 @@ int extract_one_frame_graph(orbgpu_ctx *ctx, const uint8_t *img, int stride, int
     HIP_TRY(e3);
     ctx->graph_one_features = feature_count;
   }
-  ctx->head_ok_valid = false;  // (the graph's kernels use the working buffers behind no event of the eager path)
+  // (the graph's kernels use the working set of the time of its capture behind no event of the eager path)
+  ctx->set_state[0] = ctx->set_state[1] = orbgpu_ctx::SET_BUSY;
   HIP_TRY(hipGraphLaunch(ctx->graph_one, ctx->stream));
   int rc = finish_pipeline(ctx);
   if (rc) return rc;
@@ -827,7 +860,8 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
     for (auto &ev : set)
       if (ev) (void)hipEventDestroy(ev);
   release_side_streams(ctx);
-  if (ctx->ev_head_ok) (void)hipEventDestroy(ctx->ev_head_ok);
+  for (hipEvent_t e : ctx->ev_set_free)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->ev_head_done) (void)hipEventDestroy(ctx->ev_head_done);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

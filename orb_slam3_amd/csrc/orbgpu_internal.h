@@ -184,14 +184,24 @@ struct orbgpu_ctx {
   int patch_blur_forced = -1;          // ORBGPU_PATCH_BLUR: -1 by size (patch_mode), 0 never, 1 always
   bool last_patch_mode = false;        // the last extract call blurred per keypoint (k_patch_describe): d_blur was not written
   // orbgpu_set_input_ready: the head of an orbgpu_extract_batch_device call (pyramid + FAST) on a stream of its own that
-  // waits for the caller's input event and for the previous call's last reader of the pyramid, not for the context's stream
+  // waits for the caller's input event, not for the context's stream.  What the head writes -- pyramid, cells,
+  // candidates -- exists twice then: such calls alternate between the two WORKING SETS, so a call's head shares nothing
+  // with the call before it and only waits for the last reader of its own set, two calls back (d_pyr / d_cells / d_cands
+  // always name the set of the current call; the other set's buffers are allocated by the first such call and freed
+  // by orbgpu_trim).
   bool inputs_ready = false;
   hipEvent_t input_event = nullptr;    // the caller's (not owned); nullptr: the images are complete when the call is made
   bool call_piped = false;             // this call qualifies (set by the entry point, read by run_pipeline)
   hipStream_t head_stream = nullptr;
-  hipEvent_t ev_head_ok = nullptr;     // recorded on the context's stream where a call has read its pyramid for the last time
   hipEvent_t ev_head_done = nullptr;   // this call's head is complete
-  bool head_ok_valid = false;          // ev_head_ok covers everything enqueued that touches the working buffers
+  uint8_t *d_pyr_alt = nullptr;        // the working set that is not the current call's
+  CellEntry *d_cells_alt = nullptr;
+  unsigned *d_cands_alt = nullptr;
+  int work_set = 0;                    // parity of the current set
+  enum { SET_IDLE = 0, SET_EVENT = 1, SET_BUSY = 2 };
+  // per set: nothing enqueued uses it / ev_set_free covers its last reader / in use until the context's stream drains
+  int set_state[2] = {SET_IDLE, SET_IDLE};
+  hipEvent_t ev_set_free[2] = {nullptr, nullptr};  // recorded on the context's stream where a call has read its set for the last time
   bool graph_single_frame = true;      // ORBGPU_NO_GRAPH=1: eager launches instead
   hipGraphExec_t graph_one = nullptr;  // upload + pipeline of one frame for graph_one_features keypoints
   int graph_one_features = 0;

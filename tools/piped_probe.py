@@ -13,6 +13,16 @@ base = synth.sequence(1235, 32, H, W)
 frames = np.concatenate([base] * 8)[:B]
 dev = torch.device("cuda", 0)
 d_imgs = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
+# PROBE_IDLE_CONTEXTS=n: n more contexts created (and used once) first, to see what streams that merely exist cost
+idle = []
+for _ in range(int(os.environ.get("PROBE_IDLE_CONTEXTS", "0"))):
+    fx = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, device=0, max_batch=B, max_features=NF)
+    cx = fx.geometry(NF).keypoint_capacity
+    ox = (torch.zeros((B, cx, 32), dtype=torch.uint8, device=dev), torch.zeros((B, cx, 32), dtype=torch.uint8, device=dev),
+          torch.zeros(B, dtype=torch.int32, device=dev))
+    assert lib.orbgpu_extract_batch_device(fx.handle, d_imgs.data_ptr(), W * H, W, B, NF, ox[0].data_ptr(), ox[1].data_ptr(), cx, ox[2].data_ptr()) == 0
+    assert lib.orbgpu_synchronize(fx.handle) == 0
+    idle.append(fx)
 fe = ORBFeatureExtractor(W, H, 1.2, 8, 20, 7, device=0, max_batch=B, max_features=NF)
 cap = fe.geometry(NF).keypoint_capacity
 h = fe.handle
