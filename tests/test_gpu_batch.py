@@ -477,3 +477,67 @@ def test_input_ready_gives_identical_results():
     _lib.check(lib.orbgpu_synchronize(hd), hd)
     assert same(ref[0], got[0]) and same(ref[1], got[1])
     fe.close()
+
+
+@pytest.mark.gpu
+def test_input_ready_working_sets_mixed_calls():
+    """Under orbgpu_set_input_ready a context alternates between two working sets (pyramid, cells, candidates).  THREE
+    different batches rotate through it, so that the two calls that share a set never hold the same images (a tail that
+    ran before its head had finished would otherwise reproduce the right answer from two calls back), and the calls are
+    mixed: the hint switched off and on again in between, a synchronisation, an orbgpu_trim (second set freed and
+    allocated again), a call with stage timing (never piped) and a call with another keypoint budget.  Every call's
+    outputs equal those of the same call on a context that never saw the hint."""
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import ORBFeatureExtractor
+    lib = _lib.load()
+    w, h, nf, b = 640, 480, 500, 64   # (batches long enough for a call's head to really run beside the previous tail)
+    seq = synth.sequence(909, 3 * b, h, w)
+    dev = torch.device("cuda", 0)
+    imgs = [torch.from_numpy(np.ascontiguousarray(seq[i * b:(i + 1) * b])).to(dev) for i in range(3)]
+    fe = ORBFeatureExtractor(w, h, 1.2, 8, 20, 7, max_batch=b, max_features=nf)
+    ref_fe = ORBFeatureExtractor(w, h, 1.2, 8, 20, 7, max_batch=b, max_features=nf)
+    cap = fe.geometry(nf).keypoint_capacity
+
+    def call(ctx, img, budget):
+        kp = torch.zeros((b, cap, 32), dtype=torch.uint8, device=dev)
+        desc = torch.zeros((b, cap, 32), dtype=torch.uint8, device=dev)
+        n = torch.zeros(b, dtype=torch.int32, device=dev)
+        _lib.check(lib.orbgpu_extract_batch_device(ctx.handle, img.data_ptr(), w * h, w, b, budget, kp.data_ptr(), desc.data_ptr(),
+                                                   cap, n.data_ptr()), ctx.handle)
+        return kp, desc, n
+
+    # (action, argument): "x" = extract imgs[arg] with the full budget, "x300" = with 300 keypoints
+    script = [("hint", 1), ("x", 0), ("x", 1), ("x", 2), ("x", 0), ("x", 1), ("hint", 0), ("x", 2), ("x", 0), ("hint", 1),
+              ("x", 1), ("x", 2), ("sync", 0), ("x", 0), ("x300", 1), ("x", 2), ("trim", 0), ("x", 1), ("x", 0), ("timing", 1),
+              ("x", 2), ("timing", 0), ("x", 1), ("x", 2), ("x", 0)]
+    got, want = [], []
+    torch.cuda.synchronize()
+    for act, arg in script:
+        if act == "hint":
+            _lib.check(lib.orbgpu_set_input_ready(fe.handle, arg, None), fe.handle)
+        elif act == "sync":
+            _lib.check(lib.orbgpu_synchronize(fe.handle), fe.handle)
+        elif act == "trim":
+            _lib.check(lib.orbgpu_trim(fe.handle), fe.handle)
+        elif act == "timing":
+            _lib.check(lib.orbgpu_set_stage_timing(fe.handle, arg), fe.handle)
+        else:
+            budget = 300 if act == "x300" else nf
+            got.append(call(fe, imgs[arg], budget))
+            want.append(call(ref_fe, imgs[arg], budget))
+    _lib.check(lib.orbgpu_synchronize(fe.handle), fe.handle)
+    _lib.check(lib.orbgpu_synchronize(ref_fe.handle), ref_fe.handle)
+    assert len(got) == sum(1 for a, _ in script if a.startswith("x"))
+    for i, (g_, w_) in enumerate(zip(got, want)):
+        n = w_[2].cpu().numpy()
+        assert torch.equal(g_[2], w_[2]), f"call {i}: counts"
+        gk, wk, gd, wd = g_[0].cpu().numpy(), w_[0].cpu().numpy(), g_[1].cpu().numpy(), w_[1].cpu().numpy()
+        for f in range(b):
+            assert np.array_equal(gk[f, :n[f]], wk[f, :n[f]]) and np.array_equal(gd[f, :n[f]], wd[f, :n[f]]), f"call {i}, frame {f}"
+    # the stage dump reads the working set of the last call
+    da, db = fe.debug_dump(3), ref_fe.debug_dump(3)
+    for key in ("pyramid", "score", "blurred", "cand_x", "cand_y", "cand_score"):
+        assert np.array_equal(da[key], db[key]), key
+    fe.close()
+    ref_fe.close()
