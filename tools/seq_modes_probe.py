@@ -1,5 +1,7 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""Probe: the sequence runner over 20,000 resident (and pooled) frames with one context, one context under the input-ready
+hint, and two contexts alternating.  Usage: python tools/seq_modes_probe.py"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
 import torch
 from orb_slam3_amd.features import ORBFeatureExtractor
 from orb_slam3_amd.sequence import PooledSource, ResidentSource, SequenceRunner
