@@ -704,6 +704,7 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
     HIP_TRY(hipMemcpyAsync(ctx->d_ytab, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice, ctx->stream));
     {
       std::vector<short> rs;
+      std::vector<RsColumn> rc;
       const char *rk = orbgpu_tune("resize");  // ORBGPU_RESIZE=tiles: the LDS-tiled kernel for every level
       const bool tiles = rk && std::string(rk) == "tiles";
       const char *rt = orbgpu_tune("resize_strips");  // tuning aid: strips per frame a level should reach
@@ -713,7 +714,11 @@ int orbgpu_create(const orbgpu_params *params, orbgpu_ctx **out_ctx) {
       for (int l = 1; l < g.levels; l++) {
         ctx->rs_strip_off[l] = (int)(rs.size() / 4);
         ctx->rs_items[l] = tiles ? 0 : build_resize_strips(g, l, xt.data() + g.lv[l].xtab_off, rs, rs_target);
+        ctx->rs_col_off[l] = (int)rc.size();
+        if (ctx->rs_items[l] > 0) build_resize_columns(g, l, xt.data() + g.lv[l].xtab_off, rc);
       }
+      HIP_TRY(dmalloc(&ctx->d_rs_cols, rc.size()));
+      if (!rc.empty()) HIP_TRY(hipMemcpy(ctx->d_rs_cols, rc.data(), rc.size() * sizeof(RsColumn), hipMemcpyHostToDevice));
       HIP_TRY(dmalloc(&ctx->d_rs_strips, rs.size()));
       if (!rs.empty()) HIP_TRY(hipMemcpy(ctx->d_rs_strips, rs.data(), rs.size() * sizeof(short), hipMemcpyHostToDevice));
     }
@@ -843,7 +848,7 @@ void orbgpu_destroy(orbgpu_ctx *ctx) {
   void *dptrs[] = {ctx->d_pyr, ctx->d_score, ctx->d_blur, ctx->d_xtab, ctx->d_ytab, ctx->d_cells, ctx->d_cands,
                    ctx->d_cands_packed, ctx->d_kp_xy, ctx->d_kp_count, ctx->d_kp_angle,
                    ctx->d_out_kp, ctx->d_out_desc, ctx->d_out_n, ctx->d_match_scratch, ctx->d_cands_tmp, ctx->d_cell_prefix, ctx->d_qt_nodes, ctx->d_qt_ps,
-                   ctx->d_fast_groups, ctx->d_blur_strips, ctx->d_rs_strips};
+                   ctx->d_fast_groups, ctx->d_blur_strips, ctx->d_rs_strips, ctx->d_rs_cols};
   for (void *p : dptrs)
     if (p) (void)hipFree(p);
   for (auto &n : ctx->rs_nest) {

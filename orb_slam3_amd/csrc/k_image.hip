@@ -157,8 +157,9 @@ __device__ __forceinline__ unsigned mulhi24u_s(unsigned a_uniform, unsigned b) {
   return d;
 }
 
+// cols: the level's column table (build_resize_columns): per output dword what the lane that owns it needs, ready made
 __global__ __launch_bounds__(256) void k_resize_strips(uint8_t *__restrict__ pyr, DeviceGeom g, int level,
-                                                       const XTab *__restrict__ xtab, const YTab *__restrict__ ytab,
+                                                       const RsColumn *__restrict__ cols, const YTab *__restrict__ ytab,
                                                        const short4 *__restrict__ strips, int items_per_frame, int n_frames,
                                                        Level0Src lvl0) {
   typedef unsigned short __attribute__((ext_vector_type(2))) u16x2;
@@ -173,32 +174,21 @@ __global__ __launch_bounds__(256) void k_resize_strips(uint8_t *__restrict__ pyr
   const LevelGeom &S = g.lv[level - 1], &D = g.lv[level];
   const uint8_t *src = level_src(pyr, g, lvl0, f, level - 1, S.off);
   uint8_t *dst = pyr + (size_t)f * g.frame_bytes + D.off;
-  const XTab *xt = xtab + D.xtab_off;
   const YTab *yt = ytab + D.ytab_off;
   const int dx = 4 * (d0 + lane);
-  // columns (clamped index: columns >= w are computed but masked out of the store)
-  const int sbase = xt[min(4 * d0, D.w - 1)].sx0 >> 2;  // the strip's first source dword (scalar)
-  const XTab X0 = xt[min(dx, D.w - 1)];
-  const int k0 = (X0.sx0 >> 2) - sbase;
-  const unsigned o = (unsigned)X0.sx0 & 3u;
-  unsigned sel[4], coef[4];
-#pragma unroll
-  for (int p = 0; p < 4; p++) {
-    const XTab X = xt[min(dx + p, D.w - 1)];
-    const unsigned q = (unsigned)(X.sx0 - X0.sx0) + o;  // byte of s[sx0] in the aligned 12-byte window; q - o <= 6
-    sel[p] = (q - o) | 0x0c00u | ((q - o + 1) << 16) | 0x0c000000u;
-    coef[p] = ((unsigned)X.a0 << 4) | ((unsigned)X.a1 << 20);  // (a0, a1) << 4 as u16 halves, each <= 32768
-  }
+  // columns: the lane's entry of the level's table (lanes beyond the level's last dword take that one: never stored)
+  const int sbase = cols[d0].s0;  // the strip's first source dword (scalar)
+  const RsColumn C = cols[min(d0 + lane, D.pitch / 4 - 1)];
+  const int k0 = C.s0 - sbase;
+  const unsigned o = C.o;
+  const unsigned(&sel)[4] = C.sel, (&coef)[4] = C.coef;
   const int i0 = 4 * min(k0, 63), i1 = 4 * min(k0 + 1, 63), i2 = 4 * min(k0 + 2, 63);
   // buffer loads and stores: the level's first byte is the (scalar) base, the row's offset is scalar, the lane's column a
   // 32-bit register -- no vector instruction per row for addresses
   const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, S.h * S.pitch, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(dst, 0, D.h * D.pitch, 0x00020000);
   const unsigned lcol = 4u * (unsigned)min(sbase + lane, S.pitch / 4 - 1);
-  unsigned keep = 0;
-#pragma unroll
-  for (int p = 0; p < 4; p++)
-    if (dx + p < D.w) keep |= 0xffu << (8 * p);
+  const unsigned keep = C.keep;  // bytes of the lane's dword that are pixels of the level
   const bool writes = lane < nd;
   unsigned ooff = (unsigned)(y0 * D.pitch + dx);  // the lane's byte offset into the level, next output row
 
@@ -635,7 +625,8 @@ void launch_pyramid_level(const orbgpu_ctx *c, FrameSlice fs, int level) {
   if (c->rs_items[level] > 0) {
     dim3 grid(c->rs_items[level] * xcd_frames(fs.n));
     hipLaunchKernelGGL(k_resize_strips, grid, dim3(256), 0, fs.stream, c->d_pyr + (size_t)fs.f0 * c->geom.frame_bytes, c->geom,
-                       level, c->d_xtab, c->d_ytab, reinterpret_cast<const short4 *>(c->d_rs_strips) + c->rs_strip_off[level],
+                       level, c->d_rs_cols + c->rs_col_off[level], c->d_ytab,
+                       reinterpret_cast<const short4 *>(c->d_rs_strips) + c->rs_strip_off[level],
                        c->rs_items[level], fs.n, slice_lvl0(c, fs));
     return;
   }
@@ -680,6 +671,29 @@ int build_resize_strips(const DeviceGeom &g, int level, const XTab *xt, std::vec
   for (; n % 4; n++)
     for (int q = 0; q < 4; q++) table.push_back(0);
   return n / 4;
+}
+
+// the column table of k_resize_strips: per output dword of the level (padding dwords included) the first source dword,
+// the byte offset of the first source pixel in it, per pixel the byte selector of (s[sx0], s[sx0 + 1]) in the aligned
+// 8-byte window and the weights (a0, a1) << 4, and which of the dword's bytes are pixels -- what every strip's lanes
+// used to work out from five XTab entries each
+void build_resize_columns(const DeviceGeom &g, int level, const XTab *xt, std::vector<RsColumn> &table) {
+  const LevelGeom &D = g.lv[level];
+  auto X = [&](int x) -> const XTab & { return xt[std::min(x, D.w - 1)]; };
+  for (int d = 0; d < D.pitch / 4; d++) {
+    RsColumn c{};
+    const XTab &X0 = X(4 * d);
+    c.s0 = X0.sx0 >> 2;
+    c.o = (unsigned)X0.sx0 & 3u;
+    for (int p = 0; p < 4; p++) {
+      const XTab &Xp = X(4 * d + p);
+      const unsigned q = (unsigned)(Xp.sx0 - X0.sx0);  // byte of s[sx0] in the window aligned to the quad's first pixel; <= 6
+      c.sel[p] = q | 0x0c00u | ((q + 1) << 16) | 0x0c000000u;
+      c.coef[p] = ((unsigned)Xp.a0 << 4) | ((unsigned)Xp.a1 << 20);  // (a0, a1) << 4 as u16 halves, each <= 32768
+      if (4 * d + p < D.w) c.keep |= 0xffu << (8 * p);
+    }
+    table.push_back(c);
+  }
 }
 
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs) {

@@ -69,6 +69,8 @@ __device__ __forceinline__ int level_of(const int (&offs)[ORBGPU_MAX_LEVELS], in
 // resize tables: built on the host in the exact float/double sequence
 struct XTab { int sx0, sx1; short a0, a1; };
 struct YTab { int sy0, sy1; short b0, b1; };
+// k_resize_strips: one output dword (4 pixels) of a level, as the lane that owns it needs it (48 bytes, three 16-byte loads)
+struct alignas(16) RsColumn { int s0; unsigned o, keep, pad; unsigned sel[4], coef[4]; };
 
 // packed FAST candidate: x_rel | y_rel << 12 | score << 24, coordinates relative to ORB_MIN_BORDER
 __host__ __device__ inline unsigned pack_cand(int x, int y, int s) { return (unsigned)x | ((unsigned)y << 12) | ((unsigned)s << 24); }
@@ -133,6 +135,8 @@ struct orbgpu_ctx {
   int fast_lds_rows = 0;          // tallest cell of any level: sizes the dynamic LDS of k_fast_cells
   int n_slices = 1;               // slices a batch is cut into (ORBGPU_SLICES overrides)
   short *d_rs_strips = nullptr;   // k_resize_strips: (first dword, first row, dwords, 0) per strip, level after level
+  RsColumn *d_rs_cols = nullptr;  // its column tables, level after level
+  int rs_col_off[ORBGPU_MAX_LEVELS]{};
   int rs_strip_off[ORBGPU_MAX_LEVELS]{}, rs_items[ORBGPU_MAX_LEVELS]{};  // first strip / workgroups per frame (0: k_resize_level)
   ResizeNest rs_nest[4];
   int n_rs_nest = 0;
@@ -251,6 +255,7 @@ void launch_fast_cells(const orbgpu_ctx *c, FrameSlice fs, uint8_t *score_dump, 
 void launch_blur(const orbgpu_ctx *c, FrameSlice fs);
 int build_blur_strips(const DeviceGeom &g, std::vector<short> &table);
 int build_resize_strips(const DeviceGeom &g, int level, const XTab *xt, std::vector<short> &table, int strip_target);
+void build_resize_columns(const DeviceGeom &g, int level, const XTab *xt, std::vector<RsColumn> &table);
 void launch_orient(const orbgpu_ctx *c, FrameSlice fs);
 void launch_describe(const orbgpu_ctx *c, FrameSlice fs, orbgpu_keypoint *d_kp, uint8_t *d_desc, int capacity,
                      int *d_n_out);
