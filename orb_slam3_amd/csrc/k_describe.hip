@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * KPB) void k_orient(const uint8_t *__restrict__
   int slot[KPW], lv[KPW], cx[KPW], cy[KPW];
   bool valid[KPW];
   unsigned l_off[KPW];
-  int l_pitch[KPW];
+  int l_pitch[KPW], l_bytes[KPW];
 #pragma unroll
   for (int h = 0; h < KPW; h++) {
     slot[h] = group * KPG + wave * KPW + h;
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(64 * KPB) void k_orient(const uint8_t *__restrict__
     const LevelGeom &L = g.lv[lv[h]];
     l_off[h] = L.off;
     l_pitch[h] = L.pitch;
+    l_bytes[h] = L.pitch * L.h;
     valid[h] = slot[h] < g.kps_per_frame && slot[h] - L.kp_off < cnt[lv[h]];
     cx[h] = cy[h] = 0;
   }
@@ -152,13 +153,13 @@ __global__ __launch_bounds__(64 * KPB) void k_orient(const uint8_t *__restrict__
     lvl[h] = level_src(pyr, g, lvl0, f, lv[h], l_off[h]);
   }
   unsigned ov[KPW][5];
-  orient_load<KPW>(lvl, l_pitch, cx, cy, valid, lane, ov);
+  orient_load<KPW>(lvl, l_pitch, l_bytes, cx, cy, valid, lane, ov);
   __syncthreads();  // s_tab
-  float ang[KPW];
-  orient_angles<KPW>(ov, cx, valid, s_tab, lane, ang);
+  const float ang = orient_angles<KPW>(ov, cx, valid, s_tab, lane);  // keypoint h's on lane h
+  bool mine = false;
 #pragma unroll
-  for (int h = 0; h < KPW; h++)
-    if (valid[h] && lane == 0) kp_angle[(size_t)f * g.kps_per_frame + slot[h]] = ang[h];
+  for (int h = 0; h < KPW; h++) mine = lane == h ? valid[h] : mine;
+  if (mine) kp_angle[(size_t)f * g.kps_per_frame + slot[0] + lane] = ang;
 }
 
 // k_describe: rotated BRIEF on the blurred level + the output records.  Its cost is the patch gather, so it is organised
@@ -421,10 +422,10 @@ __global__ __launch_bounds__(64 * FKPB) void k_patch_describe(const uint8_t *__r
   if (total > capacity || !any_valid) return;
   // ---- IC_Angle on the raw patches (rows 6 .. 36, columns sh + 6 .. sh + 36 of the staged patch) -----------------------
   const int osub = lane / ODW, oc = lane - osub * ODW;
-  float ang[FKPW];
+  int m10s[FKPW], m01s[FKPW];
 #pragma unroll
   for (int h = 0; h < FKPW; h++) {
-    ang[h] = 0.f;
+    m10s[h] = m01s[h] = 0;
     if (!valid[h]) continue;
     const unsigned *R = s_raw[wave * FKPW + h];
     const int osh = (sh[h] + (QR - ORB_HALF_PATCH)) & 3, odw = (sh[h] + (QR - ORB_HALF_PATCH)) >> 2;
@@ -438,18 +439,15 @@ __global__ __launch_bounds__(64 * FKPB) void k_patch_describe(const uint8_t *__r
       const unsigned rs = __builtin_amdgcn_udot4(px, ow.y, 0u, false);
       a10 = __builtin_amdgcn_udot4(px, ow.x, a10, false);
       si += rs;
-      m01 += (row - ORB_HALF_PATCH) * (int)rs;
+      m01 += __mul24(row - ORB_HALF_PATCH, (int)rs);
     }
     int m10 = (int)a10 - ORB_HALF_PATCH * (int)si;
-    m10 = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);  // (as orient_angles)
-    m01 = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
-    ang[h] = fast_atan2_deg((float)m01, (float)m10);
+    m10s[h] = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);  // (as orient_moments)
+    m01s[h] = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
   }
   // ---- cos / sin of the wave's keypoints, keypoint h on lane h (float(angle_deg) * (double)(pi / 180) -> float, cos / sin
   //      evaluated in double and rounded to float) ------------------------------------------------------
-  float my_ang = ang[0];
-#pragma unroll
-  for (int h = 1; h < FKPW; h++) my_ang = lane == h ? ang[h] : my_ang;
+  const float my_ang = orient_atan_lanes<FKPW>(m10s, m01s, lane);
   float my_cos, my_sin;
   {
     const double factorPI = 3.14159265358979323846 / 180.;
@@ -475,6 +473,7 @@ __global__ __launch_bounds__(64 * FKPB) void k_patch_describe(const uint8_t *__r
   for (int h = 0; h < FKPW; h++) {
     if (!valid[h]) continue;
     unsigned *R = s_raw[wave * FKPW + h];
+    const float ang_h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ang), h));
     const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_cos), h));
     const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sin), h));
     // ---- horizontal 7-tap, two rows at a time: lane = (row pair, dword); the neighbours' dwords by DPP.  A pair's first
@@ -544,12 +543,12 @@ __global__ __launch_bounds__(64 * FKPB) void k_patch_describe(const uint8_t *__r
         k.x *= (double)L.scale_f;
         k.y *= (double)L.scale_f;
       }
-      k.angle = ang[h];
+      k.angle = ang_h;
       k.size = L.kp_size;
       k.level = l;
       k.reserved = 0;
       out_kp[(size_t)f * capacity + pos] = k;
-      kp_angle[(size_t)f * g.kps_per_frame + slot[h]] = ang[h];
+      kp_angle[(size_t)f * g.kps_per_frame + slot[h]] = ang_h;
     }
   }
 }

@@ -50,18 +50,15 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
   const float p5 = 0.1555786518463281f * scale;
   const float p7 = -0.04432655554792128f * scale;
   const float eps = (float)DBL_EPSILON;
-  float ax = fabsf(x), ay = fabsf(y);
-  float a, c, c2;
-  if (ax >= ay) {
-    c = __fdiv_rn(ay, __fadd_rn(ax, eps));
-    c2 = __fmul_rn(c, c);
-    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-  } else {
-    c = __fdiv_rn(ax, __fadd_rn(ay, eps));
-    c2 = __fmul_rn(c, c);
-    a = __fsub_rn(90.f,
-                  __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-  }
+  const float ax = fabsf(x), ay = fabsf(y);
+  // the reference's two cases (ax >= ay: c = ay / (ax + eps); else c = ax / (ay + eps), a = 90 - poly) differ only in
+  // which magnitude is divided by which: one division and one polynomial on the selected operands are the same
+  // operations bit for bit (written as two branches the compiler evaluates both and selects)
+  const bool xm = ax >= ay;
+  const float c = __fdiv_rn(xm ? ay : ax, __fadd_rn(xm ? ax : ay, eps));
+  const float c2 = __fmul_rn(c, c);
+  const float poly = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  float a = xm ? poly : __fsub_rn(90.f, poly);
   if (x < 0) a = __fsub_rn(180.f, a);
   if (y < 0) a = __fsub_rn(360.f, a);
   return a;
@@ -69,53 +66,77 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 
 
 // IC_Angle of NK keypoints side by side by ONE wave (NK times the loads in flight), in two steps so that a caller can
-// put a barrier (the table's staging) between them.  lvl[h] / pitch[h]: the unblurred level of keypoint h; (cx, cy) and
-// valid are wave-uniform.  31 rows x 9 aligned dwords, 7 rows = 63 lanes per step.
+// put a barrier (the table's staging) between them.  lvl[h] / pitch[h] / lbytes[h]: the unblurred level of keypoint h,
+// its row pitch and size; (cx, cy) and valid are wave-uniform.  31 rows x 9 aligned dwords, 7 rows = 63 lanes per step.
+// Buffer loads: the level is the scalar base, the keypoint's patch origin and the row step of a load scalar offsets, the
+// lane's place in a 7-row group one 32-bit register -- no 64-bit address arithmetic per load.  Lane 63, the rows below
+// the disc (31 .. 34) and invalid keypoints read 0 through an offset / a range that lets nothing pass.
 template <int NK>
-__device__ __forceinline__ void orient_load(const uint8_t *const (&lvl)[NK], const int (&pitch)[NK], const int (&cx)[NK],
-                                            const int (&cy)[NK], const bool (&valid)[NK], int lane, unsigned (&ov)[NK][5]) {
+__device__ __forceinline__ void orient_load(const uint8_t *const (&lvl)[NK], const int (&pitch)[NK], const int (&lbytes)[NK],
+                                            const int (&cx)[NK], const int (&cy)[NK], const bool (&valid)[NK], int lane,
+                                            unsigned (&ov)[NK][5]) {
   const int osub = lane / ODW, oc4 = 4 * (lane - osub * ODW);
 #pragma unroll
   for (int h = 0; h < NK; h++) {
     const int xo = (cx[h] - ORB_HALF_PATCH) & ~3;
-    const uint8_t *osrc = lvl[h] + (size_t)(cy[h] - ORB_HALF_PATCH) * pitch[h] + xo;
-    const unsigned ooff = (unsigned)(osub * pitch[h] + oc4);
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(lvl[h]), 0, valid[h] ? lbytes[h] : 0, 0x00020000);
+    const unsigned voff = lane < 63 ? (unsigned)(osub * pitch[h] + oc4) : 0x80000000u;
+    const unsigned sbase = (unsigned)((cy[h] - ORB_HALF_PATCH) * pitch[h] + xo);
+    // (the last group holds rows 28 .. 34: the lanes of rows 31 .. 34 load nothing -- four cache lines per keypoint less)
+    const unsigned voff4 = 7 * 4 + osub < ORB_PATCH ? voff : 0x80000000u;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-      ov[h][k] = 0;
-      if (valid[h] && lane < 63 && 7 * k + osub < ORB_PATCH)
-        ov[h][k] = *reinterpret_cast<const unsigned *>(osrc + (ooff + (unsigned)(7 * k * pitch[h])));
-    }
+    for (int k = 0; k < 5; k++)
+      ov[h][k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, k == 4 ? voff4 : voff, sbase + (unsigned)(7 * k * pitch[h]), 0);
   }
 }
 
-// the angles from the loaded rows (every lane returns them); s_tab: the weight table in LDS
-template <int NK>
-__device__ __forceinline__ void orient_angles(const unsigned (&ov)[NK][5], const int (&cx)[NK], const bool (&valid)[NK],
-                                              const uint2 *s_tab, int lane, float (&ang)[NK]) {
+// the moments of keypoint h from its loaded rows (wave-uniform results); s_tab: the weight table in LDS
+__device__ __forceinline__ void orient_moments(const unsigned (&ov)[5], int cxh, const uint2 *s_tab, int lane, int &m10_out,
+                                               int &m01_out) {
   const int osub = lane / ODW;
+  const int osh = (cxh - ORB_HALF_PATCH) & 3;
+  unsigned a10 = 0, si = 0;
+  int m01 = 0;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    // rows beyond the disc read weight 0, lane 63 pixel 0
+    const uint2 ow = s_tab[osh * OT_STRIDE + 63 * k + min(lane, 62)];
+    const unsigned rs = __builtin_amdgcn_udot4(ov[k], ow.y, 0u, false);
+    a10 = __builtin_amdgcn_udot4(ov[k], ow.x, a10, false);
+    si += rs;
+    m01 += __mul24(7 * k + osub - ORB_HALF_PATCH, (int)rs);  // (rs <= 1020: one v_mad_i32_i24)
+  }
+  int m10 = (int)a10 - ORB_HALF_PATCH * (int)si;
+  // the wave's sums end up in lane 63 (six DPP adds each; a ds_bpermute butterfly is 18 instructions and 6 LDS ops)
+  m10_out = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);
+  m01_out = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
+}
+
+// the NK arc tangents side by side: lane h evaluates keypoint h (one fastAtan2 per wave instead of NK; the moments are
+// wave-uniform).  Returns keypoint h's angle on lane h; an invalid keypoint's moments are 0 and so is its angle
+template <int NK>
+__device__ __forceinline__ float orient_atan_lanes(const int (&m10)[NK], const int (&m01)[NK], int lane) {
+  float fx = 0.f, fy = 0.f;
 #pragma unroll
   for (int h = 0; h < NK; h++) {
-    ang[h] = 0.f;
-    if (!valid[h]) continue;
-    const int osh = (cx[h] - ORB_HALF_PATCH) & 3;
-    unsigned a10 = 0, si = 0;
-    int m01 = 0;
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-      // rows beyond the disc and lane 63 read weight 0 / pixel 0
-      const uint2 ow = s_tab[osh * OT_STRIDE + 63 * k + min(lane, 62)];
-      const unsigned rs = __builtin_amdgcn_udot4(ov[h][k], ow.y, 0u, false);
-      a10 = __builtin_amdgcn_udot4(ov[h][k], ow.x, a10, false);
-      si += rs;
-      m01 += (7 * k + osub - ORB_HALF_PATCH) * (int)rs;
-    }
-    int m10 = (int)a10 - ORB_HALF_PATCH * (int)si;
-    // the wave's sums end up in lane 63 (six DPP adds each; a ds_bpermute butterfly is 18 instructions and 6 LDS ops)
-    m10 = __builtin_amdgcn_readlane(wave_incl_scan(m10), 63);
-    m01 = __builtin_amdgcn_readlane(wave_incl_scan(m01), 63);
-    ang[h] = fast_atan2_deg((float)m01, (float)m10);
+    fx = lane == h ? (float)m10[h] : fx;
+    fy = lane == h ? (float)m01[h] : fy;
   }
+  return fast_atan2_deg(fy, fx);
+}
+
+// angles from the loaded rows: keypoint h's on lane h
+template <int NK>
+__device__ __forceinline__ float orient_angles(const unsigned (&ov)[NK][5], const int (&cx)[NK], const bool (&valid)[NK],
+                                               const uint2 *s_tab, int lane) {
+  int m10[NK], m01[NK];
+#pragma unroll
+  for (int h = 0; h < NK; h++) {
+    m10[h] = m01[h] = 0;
+    if (valid[h]) orient_moments(ov[h], cx[h], s_tab, lane, m10[h], m01[h]);
+  }
+  return orient_atan_lanes<NK>(m10, m01, lane);
 }
 
 }  // namespace orient
