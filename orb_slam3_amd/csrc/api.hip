@@ -232,6 +232,13 @@ void release_side_streams(orbgpu_ctx *ctx) {
   // (the context's stream is drained by every caller of this function: both working sets are idle, the second goes back)
   ctx->set_state[0] = ctx->set_state[1] = orbgpu_ctx::SET_IDLE;
   void *alt[3] = {ctx->d_pyr_alt, ctx->d_cells_alt, ctx->d_cands_alt};
+  if (ctx->d_pyr_alt && ctx->graph_one) {
+    // a captured one-frame graph holds the addresses of the working set of its time, which may be the one freed here:
+    // the next orbgpu_extract captures again
+    (void)hipGraphExecDestroy(ctx->graph_one);
+    ctx->graph_one = nullptr;
+    ctx->graph_one_features = 0;
+  }
   for (void *q : alt)
     if (q) (void)hipFree(q);
   ctx->d_pyr_alt = nullptr;

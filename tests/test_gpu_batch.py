@@ -541,3 +541,44 @@ def test_input_ready_working_sets_mixed_calls():
         assert np.array_equal(da[key], db[key]), key
     fe.close()
     ref_fe.close()
+
+
+@pytest.mark.gpu
+def test_one_frame_graph_survives_working_set_changes():
+    """A batch context's one-frame host call replays a captured graph that holds the addresses of the working set of the
+    time of its capture.  Calls under the input-ready hint then switch working sets and orbgpu_trim frees one of them:
+    the next one-frame call must capture again, not replay addresses that are gone."""
+    import torch
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.features import Features, ORBFeatureExtractor
+    lib = _lib.load()
+    w, h, nf, b = 640, 480, 400, 8
+    seq = synth.sequence(31, b, h, w)
+    dev = torch.device("cuda", 0)
+    d_img = torch.from_numpy(np.ascontiguousarray(seq)).to(dev)
+    fe = ORBFeatureExtractor(w, h, 1.2, 8, 20, 7, max_batch=b, max_features=nf)
+    cap = fe.geometry(nf).keypoint_capacity
+
+    def one(frame):
+        ft = Features(w, h)
+        assert fe.Extract(seq[frame], ft, nf) == 0
+        return ft
+
+    first = one(3)                       # captures the graph on working set 0
+    kp = torch.zeros((b, cap, 32), dtype=torch.uint8, device=dev)
+    desc = torch.zeros((b, cap, 32), dtype=torch.uint8, device=dev)
+    n = torch.zeros(b, dtype=torch.int32, device=dev)
+    _lib.check(lib.orbgpu_set_input_ready(fe.handle, 1, None), fe.handle)
+    for _ in range(3):                   # an odd number of switches: the context ends on the second set
+        _lib.check(lib.orbgpu_extract_batch_device(fe.handle, d_img.data_ptr(), w * h, w, b, nf, kp.data_ptr(), desc.data_ptr(),
+                                                   cap, n.data_ptr()), fe.handle)
+    again = one(3)                       # replay while both sets are alive
+    _lib.check(lib.orbgpu_set_input_ready(fe.handle, 0, None), fe.handle)
+    _lib.check(lib.orbgpu_trim(fe.handle), fe.handle)   # frees the set the graph was captured on
+    after = one(3)
+    other = one(5)
+    for ft in (again, after):
+        assert np.array_equal(first.keypoints, ft.keypoints) and np.array_equal(first.descriptors, ft.descriptors)
+    nn = int(n[5].item())
+    assert len(other.keypoints) == nn and np.array_equal(other.descriptors, desc[5, :nn].cpu().numpy())
+    fe.close()
