@@ -233,8 +233,8 @@ void release_side_streams(orbgpu_ctx *ctx) {
   ctx->set_state[0] = ctx->set_state[1] = orbgpu_ctx::SET_IDLE;
   void *alt[3] = {ctx->d_pyr_alt, ctx->d_cells_alt, ctx->d_cands_alt};
   if (ctx->d_pyr_alt && ctx->graph_one) {
-    // a captured one-frame graph holds the addresses of the working set of its time, which may be the one freed here:
-    // the next orbgpu_extract captures again
+    // (a one-frame graph captured since the last switch of working sets addresses the current one, which stays; dropped
+    //  all the same: one rule -- no graph outlives a change of the sets)
     (void)hipGraphExecDestroy(ctx->graph_one);
     ctx->graph_one = nullptr;
     ctx->graph_one_features = 0;
@@ -346,6 +346,11 @@ int run_pipeline(orbgpu_ctx *ctx, int n_frames, int feature_count, orbgpu_keypoi
     if (piped) {
       if (!ctx->head_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->head_stream, hipStreamNonBlocking));
       if (!ctx->ev_head_done) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_head_done, hipEventDisableTiming));
+      if (ctx->graph_one) {  // a captured one-frame graph addresses the set of its time: the next one-frame call captures again
+        (void)hipGraphExecDestroy(ctx->graph_one);
+        ctx->graph_one = nullptr;
+        ctx->graph_one_features = 0;
+      }
       std::swap(ctx->d_pyr, ctx->d_pyr_alt);
       std::swap(ctx->d_cells, ctx->d_cells_alt);
       std::swap(ctx->d_cands, ctx->d_cands_alt);

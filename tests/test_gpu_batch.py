@@ -572,7 +572,9 @@ def test_one_frame_graph_survives_working_set_changes():
     for _ in range(3):                   # an odd number of switches: the context ends on the second set
         _lib.check(lib.orbgpu_extract_batch_device(fe.handle, d_img.data_ptr(), w * h, w, b, nf, kp.data_ptr(), desc.data_ptr(),
                                                    cap, n.data_ptr()), fe.handle)
-    again = one(3)                       # replay while both sets are alive
+    again = one(3)                       # both sets alive, the context on the other one: captured again
+    dump = fe.debug_dump(0)              # ... so the stage dump (which reads the current set) sees this call's pyramid
+    assert np.array_equal(dump["pyramid"][:w * h].reshape(h, w), seq[3])
     _lib.check(lib.orbgpu_set_input_ready(fe.handle, 0, None), fe.handle)
     _lib.check(lib.orbgpu_trim(fe.handle), fe.handle)   # frees the set the graph was captured on
     after = one(3)
